@@ -1,0 +1,152 @@
+/* include/jetpbrt_amd.h -- C ABI of the MI355X path-tracing integrator (libjetpbrt_amd.so).
+ *
+ * Drop-in boundary.  The reference has no FFI; the seam this library sits behind is
+ *     void FIntegrator::Render(const FScene*, FSampler*, FFilm*, int numthreads) const   (integrator.h:32,
+ *     integrator.cc:35-80)  with  FPathIntegratorIteration::Li  (integrator.cc:316-403)  as the integrator.
+ * A host `Render()` (ours: jet-pbrt_amd/host/integrator.h, FGpuPathIntegrator::Render) flattens the
+ * preprocessed FScene into the plain arrays of JpScene and calls the entry points below instead of spawning
+ * the 20-row CPU tasks of integrator.cc:53-74 / parallel.cc.
+ *
+ * Conventions: plain C types only; every function returns JP_OK (0) or a negative JpStatus and never throws;
+ * jp_last_error() returns a thread-local message for the last failure.  The caller owns every host buffer;
+ * the context owns all device memory.  All floats are IEEE binary32 ("Float" = float, pbrt.h:27).
+ * Arrays of points/vectors/colours are tightly packed xyz / rgb triples.
+ */
+#ifndef JETPBRT_AMD_H
+#define JETPBRT_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JP_ABI_VERSION 1
+
+typedef enum JpStatus {
+    JP_OK = 0,
+    JP_ERR_INVALID_ARGUMENT = -1,   /* null pointer, bad enum, index out of range, malformed BVH ... */
+    JP_ERR_NO_DEVICE = -2,          /* no HIP device / device id out of range                         */
+    JP_ERR_DEVICE = -3,             /* a HIP runtime call failed (message has the hipError string)    */
+    JP_ERR_NO_SCENE = -4,           /* jp_render before jp_upload_scene                               */
+    JP_ERR_UNSUPPORTED = -5         /* e.g. sampler mode the device path cannot reproduce             */
+} JpStatus;
+
+/* shape kinds: FTriangle shape.h:277-369, FRectangle shape.h:380-472, FSphere shape.h:476-662 */
+enum { JP_SHAPE_TRIANGLE = 0, JP_SHAPE_RECTANGLE = 1, JP_SHAPE_SPHERE = 2 };
+/* material kinds: material.h:27-41 (matte), :45-59 (mirror), :63-81 (glass), :85-110 + material.cc:12-29
+ * (plastic), material.h:113-137 + material.cc:31-43 (metal) */
+enum { JP_MAT_MATTE = 0, JP_MAT_MIRROR = 1, JP_MAT_GLASS = 2, JP_MAT_PLASTIC = 3, JP_MAT_METAL = 4 };
+/* light kinds: FEnvironmentLight light.h:248-311, FAreaLight light.h:183-244 */
+enum { JP_LIGHT_ENVIRONMENT = 0, JP_LIGHT_AREA = 1 };
+/* sampler: the stock sequential mt19937_64 stream (sampler.h:16-54) cannot be reproduced by a parallel
+ * device; the device path implements the counter-based stream of include/jp_counter_rng.h only. */
+enum { JP_SAMPLER_STOCK_MT19937 = 0, JP_SAMPLER_COUNTER = 1 };
+
+#define JP_MAT_PARAM_STRIDE 16
+/* mat_params layout, JP_MAT_PARAM_STRIDE floats per material (the state the reference material objects hold):
+ *   MATTE   [0..2] diffuseColor                                                     material.h:29-40
+ *   MIRROR  [0..2] specularColor                                                    material.h:47-58
+ *   GLASS   [0] eta, [1..3] Kr, [4..6] Kt                                           material.h:65-80
+ *   PLASTIC [0..2] Kd, [3..5] Ks, [6] alpha (roughness after the optional remap), [7] Qd      material.h:88-109
+ *   METAL   [0..2] eta, [3..5] k, [6] alpha_x, [7] alpha_y (after the optional remap)         material.h:116-136
+ */
+
+/* FCamera state after its constructor (camera.h:36-49): right/up already scaled by tan(fov/2) (and aspect). */
+typedef struct JpCamera {
+    float pos[3], front[3], right[3], up[3];
+    float res_x, res_y;
+} JpCamera;
+
+typedef struct JpScene {
+    JpCamera camera;
+
+    /* shapes, SoA */
+    int32_t n_triangles;   const float *tri_p0, *tri_p1, *tri_p2, *tri_n;              /* n = FTriangle::normal (flip applied) */
+    int32_t n_rectangles;  const float *rect_p0, *rect_p1, *rect_p2, *rect_p3, *rect_n;
+    int32_t n_spheres;     const float *sph_center; const float *sph_radius;
+
+    /* primitives (FPrimitive, primitive.h:20-64) in creation order == FScene::shadow_primitives before Preprocess */
+    int32_t n_primitives;
+    const int32_t *prim_shape_type;    /* JP_SHAPE_*                                    */
+    const int32_t *prim_shape_index;   /* index into the arrays of that shape kind      */
+    const int32_t *prim_material;      /* material index, -1 = nullptr material         */
+    const int32_t *prim_light;         /* index into lights (FPrimitive::arealight), -1 = none */
+
+    int32_t n_materials;   const int32_t *mat_type; const float *mat_params;
+
+    /* lights in FScene::Lights() order (creation order; scene.h:92-106) */
+    int32_t n_lights;
+    const int32_t *light_type;         /* JP_LIGHT_*                                    */
+    const float   *light_radiance;     /* rgb                                            */
+    const int32_t *light_prim;         /* AREA: primitive whose shape emits; ENVIRONMENT: -1 */
+    float world_radius;                /* FEnvironmentLight::worldRadius after Preprocess (light.cc:26-33) */
+
+    /* bounding volume hierarchy over the primitives, built by the host (own topology; closest-hit and
+     * occlusion results do not depend on it).  Node i: bounds 6 floats (min xyz, max xyz);
+     * bvh_left[i] >= 0: interior, children bvh_left[i], bvh_right[i];
+     * bvh_left[i] <  0: leaf, primitives bvh_prim_index[first .. first+count) with first = -bvh_left[i]-1,
+     *                   count = bvh_right[i].  Node 0 is the root. */
+    int32_t n_bvh_nodes;   const float *bvh_bounds; const int32_t *bvh_left, *bvh_right;
+    int32_t n_bvh_prim_indices; const int32_t *bvh_prim_index;
+} JpScene;
+
+typedef struct JpRenderParams {
+    int32_t width, height;       /* film size == camera resolution (main.cc:115)                          */
+    int32_t spp;                 /* FSampler::samples_per_pixel                                           */
+    int32_t max_depth;           /* FPathIntegratorIteration::maxDepth (main.cc:154: 5)                   */
+    int32_t sampler_mode;        /* JP_SAMPLER_*                                                          */
+    uint32_t seed;               /* counter sampler seed                                                  */
+    /* pixel-band sharding (multi-GPU): the film is cut into bands of `band_rows` rows -- the unit of
+     * FRenderTask, lines_per_task = 20, integrator.cc:53 -- and this call renders band b iff
+     * b % shard_count == shard_index.  Pixels outside the shard are written as 0, so the sum over shards
+     * (one RCCL reduce) is the full film.  shard_count <= 1 renders everything. */
+    int32_t band_rows, shard_index, shard_count;
+    int32_t reserved;
+} JpRenderParams;
+
+typedef struct JpCounters {
+    uint64_t samples;            /* camera samples traced                                                 */
+    uint64_t closest_rays;       /* FScene::Intersect calls from Li (integrator.cc:327)                   */
+    uint64_t closest_hits;
+    uint64_t shadow_rays;        /* FScene::Occluded calls (integrator.cc:367)                            */
+    uint64_t shadow_occluded;
+    double   render_ms;          /* device time of the last jp_render*, HIP events on the context stream  */
+    double   extend_ms, shade_ms, shadow_ms, other_ms;   /* per kernel class, when profiling is enabled   */
+    uint64_t extend_launches, shade_launches, shadow_launches;
+} JpCounters;
+
+typedef struct JpContext JpContext;
+
+const char* jp_last_error(void);
+int  jp_abi_version(void);
+
+/* one context per process per GPU (device_id = LOCAL_RANK) */
+int  jp_create_context(int device_id, JpContext** out);
+int  jp_destroy_context(JpContext* ctx);
+
+/* validates every index in `scene` on the host, then copies it into device-resident SoA tables */
+int  jp_upload_scene(JpContext* ctx, const JpScene* scene);
+
+/* replaces FIntegrator::Render (integrator.cc:35-80): blocking; fills film_rgb (width*height*3 floats,
+ * row-major, top row first, film.h:51-57) with Clamp01(sum_s Li_s / spp) (integrator.cc:89-108).
+ * Values are SET, i.e. the result of AddColor onto the zero-initialised film of film.h:30-35. */
+int  jp_render(JpContext* ctx, const JpRenderParams* params, float* film_rgb_host);
+/* same, film left in device memory (film_rgb_device must hold width*height*3 floats on ctx's device);
+ * asynchronous on the context stream unless `sync` != 0.  Used for the multi-GPU reduce. */
+int  jp_render_device(JpContext* ctx, const JpRenderParams* params, void* film_rgb_device, int sync);
+int  jp_synchronize(JpContext* ctx);
+
+/* per-kernel-class event timing (adds two events per launch); off by default */
+int  jp_set_profiling(JpContext* ctx, int enabled);
+int  jp_get_counters(JpContext* ctx, JpCounters* out);
+
+/* test hook: closest-hit query for n rays (FScene::Intersect, scene.cc:25-33).  Host arrays:
+ * origin/dir 3n floats, tmin/tmax n floats -> hit (0/1), t (ray.max_t after the call), prim (-1 if none),
+ * normal 3n floats (FIntersection::normal).  Runs the same device traversal the render uses. */
+int  jp_trace(JpContext* ctx, int32_t n, const float* origin, const float* dir, const float* tmin, const float* tmax,
+              int32_t* hit, float* t, int32_t* prim, float* normal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

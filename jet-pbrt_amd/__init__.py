@@ -1,0 +1,184 @@
+"""jet-pbrt_amd -- MI355X-native path-tracing integrator behind jet-pbrt's Render() seam.
+
+Python here is plumbing only (ctypes bindings for tests / bench / smoke): the product is
+  * csrc/libjetpbrt_amd.so   hand-written HIP wavefront kernels + the C ABI of include/jetpbrt_amd.h
+  * host/libjetpbrt_host.so  C++ mirror of the reference's FScene/FCamera/FFilm/FSampler/FMaterial/
+                             FIntegrator::Render API, BVH builder and scene flattener.
+Nothing in this package imports, links or calls anything under oracle/ (test infrastructure).
+The directory name has a hyphen; import it as `jet_pbrt_amd` (shim module at the repo root).
+"""
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+HIP_LIB_PATH = os.path.join(PKG_DIR, "csrc", "libjetpbrt_amd.so")
+HOST_LIB_PATH = os.path.join(PKG_DIR, "host", "libjetpbrt_host.so")
+
+JP_MAT_PARAM_STRIDE = 16
+JP_SAMPLER_STOCK_MT19937, JP_SAMPLER_COUNTER = 0, 1
+JP_OK = 0
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+class JpCamera(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("front", C.c_float * 3), ("right", C.c_float * 3), ("up", C.c_float * 3),
+                ("res_x", C.c_float), ("res_y", C.c_float)]
+
+
+class JpScene(C.Structure):
+    _fields_ = [
+        ("camera", JpCamera),
+        ("n_triangles", C.c_int32), ("tri_p0", _fp), ("tri_p1", _fp), ("tri_p2", _fp), ("tri_n", _fp),
+        ("n_rectangles", C.c_int32), ("rect_p0", _fp), ("rect_p1", _fp), ("rect_p2", _fp), ("rect_p3", _fp), ("rect_n", _fp),
+        ("n_spheres", C.c_int32), ("sph_center", _fp), ("sph_radius", _fp),
+        ("n_primitives", C.c_int32), ("prim_shape_type", _ip), ("prim_shape_index", _ip), ("prim_material", _ip), ("prim_light", _ip),
+        ("n_materials", C.c_int32), ("mat_type", _ip), ("mat_params", _fp),
+        ("n_lights", C.c_int32), ("light_type", _ip), ("light_radiance", _fp), ("light_prim", _ip),
+        ("world_radius", C.c_float),
+        ("n_bvh_nodes", C.c_int32), ("bvh_bounds", _fp), ("bvh_left", _ip), ("bvh_right", _ip),
+        ("n_bvh_prim_indices", C.c_int32), ("bvh_prim_index", _ip),
+    ]
+
+
+class JpRenderParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
+                ("sampler_mode", C.c_int32), ("seed", C.c_uint32),
+                ("band_rows", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("reserved", C.c_int32)]
+
+
+class JpCounters(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("closest_hits", C.c_uint64),
+                ("shadow_rays", C.c_uint64), ("shadow_occluded", C.c_uint64),
+                ("render_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("shadow_ms", C.c_double),
+                ("other_ms", C.c_double),
+                ("extend_launches", C.c_uint64), ("shade_launches", C.c_uint64), ("shadow_launches", C.c_uint64)]
+
+
+def render_params(width, height, spp, max_depth=5, seed=1234, sampler_mode=JP_SAMPLER_COUNTER,
+                  band_rows=20, shard_index=0, shard_count=1):
+    return JpRenderParams(width, height, spp, max_depth, sampler_mode, seed, band_rows, shard_index, shard_count, 0)
+
+
+class JetPbrtError(RuntimeError):
+    pass
+
+
+_host = None
+_hip = None
+
+
+def host_lib():
+    """libjetpbrt_host.so (C++ host mirror + flattener).  Raises if it has not been built."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise JetPbrtError("host library missing: %s (run __graft_entry__.build())" % HOST_LIB_PATH)
+        L = C.CDLL(HOST_LIB_PATH)
+        L.jp_host_scene_new.restype = C.c_void_p
+        L.jp_host_scene_new.argtypes = [C.c_char_p]
+        L.jp_host_scene_free.argtypes = [C.c_void_p]
+        L.jp_host_last_error.restype = C.c_char_p
+        L.jp_host_last_error.argtypes = [C.c_void_p]
+        L.jp_host_scene_camera.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float]
+        L.jp_host_scene_envlight.argtypes = [C.c_void_p, _fp]
+        L.jp_host_mat_matte.argtypes = [C.c_void_p, _fp]
+        L.jp_host_mat_mirror.argtypes = [C.c_void_p, _fp]
+        L.jp_host_mat_glass.argtypes = [C.c_void_p, C.c_float, _fp, _fp]
+        L.jp_host_mat_plastic.argtypes = [C.c_void_p, _fp, _fp, C.c_float, C.c_int]
+        L.jp_host_mat_metal.argtypes = [C.c_void_p, _fp, _fp, C.c_float, C.c_float, C.c_int]
+        L.jp_host_scene_mesh.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, _fp, C.c_float, C.c_int, _fp]
+        L.jp_host_scene_rect.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _fp]
+        L.jp_host_scene_sphere.argtypes = [C.c_void_p, _fp, C.c_float, C.c_int, _fp]
+        L.jp_host_scene_preprocess.argtypes = [C.c_void_p]
+        L.jp_host_num_primitives.argtypes = [C.c_void_p]
+        L.jp_host_num_lights.argtypes = [C.c_void_p]
+        L.jp_host_flatten.restype = C.POINTER(JpScene)
+        L.jp_host_flatten.argtypes = [C.c_void_p]
+        L.jp_host_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.POINTER(JpCounters)]
+        _host = L
+    return _host
+
+
+def hip_lib():
+    """libjetpbrt_amd.so (HIP kernels + C ABI).  Raises loudly if missing: there is no CPU fallback."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise JetPbrtError("HIP library missing: %s (run __graft_entry__.build()); the product has no CPU fallback" % HIP_LIB_PATH)
+        L = C.CDLL(HIP_LIB_PATH)
+        L.jp_last_error.restype = C.c_char_p
+        L.jp_create_context.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.jp_destroy_context.argtypes = [C.c_void_p]
+        L.jp_upload_scene.argtypes = [C.c_void_p, C.POINTER(JpScene)]
+        L.jp_render.argtypes = [C.c_void_p, C.POINTER(JpRenderParams), C.c_void_p]
+        L.jp_render_device.argtypes = [C.c_void_p, C.POINTER(JpRenderParams), C.c_void_p, C.c_int]
+        L.jp_synchronize.argtypes = [C.c_void_p]
+        L.jp_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.jp_get_counters.argtypes = [C.c_void_p, C.POINTER(JpCounters)]
+        L.jp_trace.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 8
+        _hip = L
+    return _hip
+
+
+class Context:
+    """Thin RAII wrapper over JpContext for harness code."""
+
+    def __init__(self, device_id=0):
+        self.lib = hip_lib()
+        self.h = C.c_void_p()
+        self._check(self.lib.jp_create_context(device_id, C.byref(self.h)))
+
+    def _check(self, st):
+        if st != JP_OK:
+            raise JetPbrtError("jetpbrt_amd status %d: %s" % (st, self.lib.jp_last_error().decode()))
+
+    def upload(self, scene_ptr):
+        self._check(self.lib.jp_upload_scene(self.h, scene_ptr))
+
+    def render(self, params):
+        import numpy as np
+        film = np.zeros((params.height, params.width, 3), np.float32)
+        self._check(self.lib.jp_render(self.h, C.byref(params), film.ctypes.data_as(C.c_void_p)))
+        return film
+
+    def render_device(self, params, device_ptr, sync=False):
+        self._check(self.lib.jp_render_device(self.h, C.byref(params), C.c_void_p(device_ptr), 1 if sync else 0))
+
+    def synchronize(self):
+        self._check(self.lib.jp_synchronize(self.h))
+
+    def set_profiling(self, on):
+        self._check(self.lib.jp_set_profiling(self.h, 1 if on else 0))
+
+    def counters(self):
+        c = JpCounters()
+        self._check(self.lib.jp_get_counters(self.h, C.byref(c)))
+        return c
+
+    def trace(self, origin, direction, tmin, tmax):
+        import numpy as np
+        n = origin.shape[0]
+        o = np.ascontiguousarray(origin, np.float32); d = np.ascontiguousarray(direction, np.float32)
+        t0 = np.ascontiguousarray(tmin, np.float32); t1 = np.ascontiguousarray(tmax, np.float32)
+        hit = np.zeros(n, np.int32); t = np.zeros(n, np.float32); prim = np.zeros(n, np.int32); nrm = np.zeros((n, 3), np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(self.lib.jp_trace(self.h, n, p(o), p(d), p(t0), p(t1), p(hit), p(t), p(prim), p(nrm)))
+        return hit, t, prim, nrm
+
+    def close(self):
+        if self.h:
+            self.lib.jp_destroy_context(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+from . import scenes  # noqa: E402,F401

@@ -1,0 +1,124 @@
+// jet-pbrt_amd/host/bvh_build.cc -- binned-SAH BVH builder producing the flat node arrays of JpScene.
+//
+// Replaces the reference's build (bvh.h:54-91: random split axis from rand(), std::sort, median split,
+// leaves <= 5) with a surface-area-heuristic build: the device traversal is ordered with early-out, so tree
+// quality matters, and closest-hit / occlusion RESULTS do not depend on topology.
+// Nodes are emitted in depth-first order (left child = parent + 1) for locality.
+#include "jetpbrt.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace jetpbrt
+{
+namespace
+{
+struct B { float mn[3], mx[3]; };
+inline B emptyB() { B b; for (int a = 0; a < 3; a++) { b.mn[a] = std::numeric_limits<float>::max(); b.mx[a] = std::numeric_limits<float>::lowest(); } return b; }
+inline void grow(B& b, const B& o) { for (int a = 0; a < 3; a++) { b.mn[a] = std::min(b.mn[a], o.mn[a]); b.mx[a] = std::max(b.mx[a], o.mx[a]); } }
+inline void growP(B& b, const float* p) { for (int a = 0; a < 3; a++) { b.mn[a] = std::min(b.mn[a], p[a]); b.mx[a] = std::max(b.mx[a], p[a]); } }
+inline float area(const B& b)
+{
+	float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+	if (dx < 0 || dy < 0 || dz < 0) return 0.f;
+	return 2.f * (dx * dy + dy * dz + dz * dx);
+}
+
+struct Builder
+{
+	const std::vector<B>& pb; std::vector<float> cen; std::vector<int32_t> idx; FlatBVH& out; int maxLeaf;
+	Builder(const std::vector<B>& pb, FlatBVH& out, int maxLeaf) : pb(pb), out(out), maxLeaf(maxLeaf)
+	{
+		idx.resize(pb.size()); cen.resize(pb.size() * 3);
+		for (size_t i = 0; i < pb.size(); i++) { idx[i] = (int32_t)i; for (int a = 0; a < 3; a++) cen[3 * i + a] = 0.5f * (pb[i].mn[a] + pb[i].mx[a]); }
+	}
+	int emit(const B& b)
+	{
+		int n = (int)out.left.size();
+		out.left.push_back(0); out.right.push_back(0);
+		for (int a = 0; a < 3; a++) out.bounds.push_back(b.mn[a]);
+		for (int a = 0; a < 3; a++) out.bounds.push_back(b.mx[a]);
+		return n;
+	}
+	void leaf(int node, int start, int end)
+	{
+		int first = (int)out.prim_index.size();
+		for (int i = start; i < end; i++) out.prim_index.push_back(idx[i]);
+		out.left[node] = -first - 1; out.right[node] = end - start;
+	}
+	int build(int start, int end)
+	{
+		B nb = emptyB(), cb = emptyB();
+		for (int i = start; i < end; i++) { grow(nb, pb[idx[i]]); growP(cb, &cen[3 * idx[i]]); }
+		int node = emit(nb);
+		int n = end - start;
+		if (n <= 1) { leaf(node, start, end); return node; }
+
+		// binned SAH over the centroid bounds, all three axes
+		const int NB = 16;
+		float bestCost = std::numeric_limits<float>::max(); int bestAxis = -1, bestBin = -1;
+		for (int a = 0; a < 3; a++)
+		{
+			float lo = cb.mn[a], hi = cb.mx[a];
+			if (!(hi > lo)) continue;
+			B bins[NB]; int cnt[NB];
+			for (int k = 0; k < NB; k++) { bins[k] = emptyB(); cnt[k] = 0; }
+			float scale = NB / (hi - lo);
+			for (int i = start; i < end; i++)
+			{
+				int k = (int)((cen[3 * idx[i] + a] - lo) * scale); if (k >= NB) k = NB - 1; if (k < 0) k = 0;
+				grow(bins[k], pb[idx[i]]); cnt[k]++;
+			}
+			float rightArea[NB]; int rightCnt[NB];
+			B acc = emptyB(); int c = 0;
+			for (int k = NB - 1; k > 0; k--) { grow(acc, bins[k]); c += cnt[k]; rightArea[k] = area(acc); rightCnt[k] = c; }
+			acc = emptyB(); c = 0;
+			for (int k = 0; k < NB - 1; k++)
+			{
+				grow(acc, bins[k]); c += cnt[k];
+				if (c == 0 || rightCnt[k + 1] == 0) continue;
+				float cost = area(acc) * c + rightArea[k + 1] * rightCnt[k + 1];
+				if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = k; }
+			}
+		}
+		float leafCost = area(nb) * n;
+		int mid = -1;
+		if (bestAxis >= 0 && (n > maxLeaf || bestCost + area(nb) * 1.0f < leafCost))
+		{
+			float lo = cb.mn[bestAxis], hi = cb.mx[bestAxis]; float scale = NB / (hi - lo);
+			int a = bestAxis, bb = bestBin;
+			int32_t* p = std::partition(idx.data() + start, idx.data() + end, [&](int32_t i) {
+				int k = (int)((cen[3 * i + a] - lo) * scale); if (k >= NB) k = NB - 1; if (k < 0) k = 0; return k <= bb; });
+			mid = (int)(p - idx.data());
+		}
+		if (mid <= start || mid >= end)
+		{
+			if (n <= maxLeaf) { leaf(node, start, end); return node; }
+			// degenerate centroids: median split on the widest node axis
+			int a = 0; float w = -1; for (int k = 0; k < 3; k++) if (nb.mx[k] - nb.mn[k] > w) { w = nb.mx[k] - nb.mn[k]; a = k; }
+			mid = start + n / 2;
+			std::nth_element(idx.begin() + start, idx.begin() + mid, idx.begin() + end, [&](int32_t x, int32_t y) { return cen[3 * x + a] < cen[3 * y + a]; });
+		}
+		int l = build(start, mid);
+		int r = build(mid, end);
+		out.left[node] = l; out.right[node] = r;
+		return node;
+	}
+};
+}
+
+void BuildBVH(const std::vector<FBounds3>& primBounds, FlatBVH& out, int maxLeaf)
+{
+	out = FlatBVH();
+	if (primBounds.empty()) return;
+	std::vector<B> pb(primBounds.size());
+	for (size_t i = 0; i < pb.size(); i++)
+	{
+		pb[i].mn[0] = primBounds[i]._min.x; pb[i].mn[1] = primBounds[i]._min.y; pb[i].mn[2] = primBounds[i]._min.z;
+		pb[i].mx[0] = primBounds[i]._max.x; pb[i].mx[1] = primBounds[i]._max.y; pb[i].mx[2] = primBounds[i]._max.z;
+	}
+	Builder b(pb, out, maxLeaf);
+	b.build(0, (int)pb.size());
+}
+
+} // namespace jetpbrt

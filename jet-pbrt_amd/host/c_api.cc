@@ -1,0 +1,95 @@
+// jet-pbrt_amd/host/c_api.cc -- a procedural C view of the host API (jp_host_*), so that Python harnesses
+// (tests, bench.py, __graft_entry__) can build scenes through the SAME call sequence they use on the compiled
+// reference (oracle/ref_build/ref_driver.cc: ref_*), i.e. the calls of main.cc:13-111.
+#include "jetpbrt.h"
+
+#include <cstring>
+
+using namespace jetpbrt;
+
+namespace
+{
+struct HostScene
+{
+	std::shared_ptr<FScene> scene;
+	std::vector<std::shared_ptr<FMaterial>> mats;
+	FlatScene flat; bool flattened = false;
+	std::unique_ptr<FGpuPathIntegrator> integ; int integDepth = -1;
+	std::string error;
+};
+FColor C3(const float* v) { return FColor(v[0], v[1], v[2]); }
+FVector3 V3(const float* v) { return FVector3(v[0], v[1], v[2]); }
+void attach(HostScene* hs, const std::shared_ptr<FShape>& shape, int mat, const float* radiance)
+{
+	std::shared_ptr<FMaterial> m = mat >= 0 ? hs->mats[mat] : nullptr;
+	if (radiance) hs->scene->CreateAreaLight(1, C3(radiance), shape, m);
+	else hs->scene->CreatePrimitive(shape.get(), m.get(), (const FAreaLight*)nullptr);
+}
+}
+
+extern "C" {
+
+void* jp_host_scene_new(const char* name) { HostScene* hs = new HostScene; hs->scene = std::make_shared<FScene>(name); return hs; }
+void  jp_host_scene_free(void* h) { delete (HostScene*)h; }
+const char* jp_host_last_error(void* h) { return ((HostScene*)h)->error.c_str(); }
+
+void jp_host_scene_camera(void* h, const float* lookfrom, const float* front, const float* up, float vfov, float resx, float resy)
+{ ((HostScene*)h)->scene->CreateCamera<FCamera>(V3(lookfrom), V3(front), V3(up), vfov, FVector2(resx, resy)); }
+
+int jp_host_scene_envlight(void* h, const float* rgb)
+{ HostScene* hs = (HostScene*)h; hs->scene->CreateLight<FEnvironmentLight>(FPoint3(0, 0, 0), 1, C3(rgb)); return hs->scene->LightNum() - 1; }
+
+int jp_host_mat_matte(void* h, const float* rgb) { HostScene* hs = (HostScene*)h; hs->mats.push_back(hs->scene->CreateMaterial<FMatteMaterial>(C3(rgb))); return (int)hs->mats.size() - 1; }
+int jp_host_mat_mirror(void* h, const float* rgb) { HostScene* hs = (HostScene*)h; hs->mats.push_back(hs->scene->CreateMaterial<FMirrorMaterial>(C3(rgb))); return (int)hs->mats.size() - 1; }
+int jp_host_mat_glass(void* h, float eta, const float* kr, const float* kt) { HostScene* hs = (HostScene*)h; hs->mats.push_back(hs->scene->CreateMaterial<FGlassMaterial>(eta, C3(kr), C3(kt))); return (int)hs->mats.size() - 1; }
+int jp_host_mat_plastic(void* h, const float* kd, const float* ks, float rough, int remap) { HostScene* hs = (HostScene*)h; hs->mats.push_back(hs->scene->CreateMaterial<FPlasticMaterial>(C3(kd), C3(ks), rough, remap != 0)); return (int)hs->mats.size() - 1; }
+int jp_host_mat_metal(void* h, const float* eta, const float* k, float ur, float vr, int remap) { HostScene* hs = (HostScene*)h; hs->mats.push_back(hs->scene->CreateMaterial<FMetalMaterial>(C3(eta), C3(k), ur, vr, remap != 0)); return (int)hs->mats.size() - 1; }
+
+int jp_host_scene_mesh(void* h, const char* path, int flip_normal, int flip_handedness, const float* offset, float scale, int mat, const float* radiance)
+{
+	HostScene* hs = (HostScene*)h;
+	std::vector<std::shared_ptr<FShape>> mesh = hs->scene->CreateTriangleMesh(path, flip_normal != 0, flip_handedness != 0, V3(offset), scale);
+	std::shared_ptr<FMaterial> m = mat >= 0 ? hs->mats[mat] : nullptr;
+	if (radiance) hs->scene->CreateAreaLights(1, C3(radiance), mesh, m);
+	else hs->scene->CreatePrimitives(mesh, m);
+	return (int)mesh.size();
+}
+
+void jp_host_scene_rect(void* h, int axis, float a0, float a1, float b0, float b1, float c, int flip, int mat, const float* radiance)
+{
+	HostScene* hs = (HostScene*)h;
+	FRectangle r = axis == 0 ? FRectangle::FromXY(a0, a1, b0, b1, c, flip != 0) : axis == 1 ? FRectangle::FromXZ(a0, a1, b0, b1, c, flip != 0) : FRectangle::FromYZ(a0, a1, b0, b1, c, flip != 0);
+	attach(hs, hs->scene->CreateShape<FRectangle>(r), mat, radiance);
+}
+
+void jp_host_scene_sphere(void* h, const float* center, float radius, int mat, const float* radiance)
+{ HostScene* hs = (HostScene*)h; attach(hs, hs->scene->CreateShape<FSphere>(V3(center), radius), mat, radiance); }
+
+void jp_host_scene_preprocess(void* h) { HostScene* hs = (HostScene*)h; hs->scene->Preprocess(); hs->flattened = false; }
+int  jp_host_num_primitives(void* h) { return (int)((HostScene*)h)->scene->primitives.size(); }
+int  jp_host_num_lights(void* h) { return ((HostScene*)h)->scene->LightNum(); }
+
+// the flattened SoA view (owned by the handle; valid until the next preprocess/free)
+const JpScene* jp_host_flatten(void* h)
+{
+	HostScene* hs = (HostScene*)h;
+	if (!hs->flattened) { if (!FlattenScene(*hs->scene, hs->flat, &hs->error)) return nullptr; hs->flattened = true; }
+	return &hs->flat.view;
+}
+
+// FGpuPathIntegrator(maxdepth).Render(scene, FCounterSampler(spp, seed), film, numthreads) -> rgb (added onto zeros)
+int jp_host_render(void* h, int W, int H, int spp, int maxdepth, unsigned seed, int device, int shard_index, int shard_count, float* film_out, JpCounters* counters)
+{
+	HostScene* hs = (HostScene*)h;
+	if (!hs->integ || hs->integDepth != maxdepth) { hs->integ.reset(new FGpuPathIntegrator(maxdepth, device)); hs->integDepth = maxdepth; }
+	hs->integ->SetShard(shard_index, shard_count > 0 ? shard_count : 1);
+	FFilm film(W, H);
+	FCounterSampler sampler(spp, seed);
+	hs->integ->Render(hs->scene.get(), &sampler, &film, 16);
+	if (hs->integ->LastStatus() != JP_OK) return hs->integ->LastStatus();
+	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const FColor& c = film(x, y); float* o = film_out + 3 * ((size_t)y * W + x); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
+	if (counters) *counters = hs->integ->Counters();
+	return JP_OK;
+}
+
+} // extern "C"

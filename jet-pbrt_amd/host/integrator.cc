@@ -1,0 +1,93 @@
+// jet-pbrt_amd/host/integrator.cc -- FGpuPathIntegrator::Render: the replacement for the reference's
+// FIntegrator::Render (integrator.cc:35-80).  Instead of cutting the film into 20-row FRenderTasks for a
+// std::thread pool (integrator.cc:53-74, parallel.cc), it flattens the scene once and calls the HIP library
+// through the C ABI of include/jetpbrt_amd.h.  The HIP library is bound with dlopen so this host library has no
+// link-time GPU dependency; if it is missing Render() fails loudly -- there is no CPU fallback.
+#include "jetpbrt.h"
+
+#include <dlfcn.h>
+#include <cstring>
+#include <mutex>
+
+namespace jetpbrt
+{
+namespace
+{
+struct HipApi
+{
+	void* lib = nullptr;
+	const char* (*last_error)() = nullptr;
+	int (*create_context)(int, JpContext**) = nullptr;
+	int (*destroy_context)(JpContext*) = nullptr;
+	int (*upload_scene)(JpContext*, const JpScene*) = nullptr;
+	int (*render)(JpContext*, const JpRenderParams*, float*) = nullptr;
+	int (*get_counters)(JpContext*, JpCounters*) = nullptr;
+	std::string error;
+};
+
+HipApi& Api()
+{
+	static HipApi api; static std::once_flag once;
+	std::call_once(once, []() {
+		// libjetpbrt_amd.so lives next to this library's directory: <pkg>/csrc/libjetpbrt_amd.so
+		std::string dir;
+		Dl_info info;
+		if (dladdr((void*)&Api, &info) && info.dli_fname) { dir = info.dli_fname; size_t p = dir.find_last_of('/'); dir = p == std::string::npos ? "." : dir.substr(0, p); }
+		const char* env = getenv("JETPBRT_AMD_LIB");
+		std::string cands[3] = { env ? env : "", dir + "/../csrc/libjetpbrt_amd.so", "libjetpbrt_amd.so" };
+		for (auto& c : cands) { if (c.empty()) continue; api.lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL); if (api.lib) break; api.error = dlerror(); }
+		if (!api.lib) return;
+		api.last_error = (const char* (*)())dlsym(api.lib, "jp_last_error");
+		api.create_context = (int (*)(int, JpContext**))dlsym(api.lib, "jp_create_context");
+		api.destroy_context = (int (*)(JpContext*))dlsym(api.lib, "jp_destroy_context");
+		api.upload_scene = (int (*)(JpContext*, const JpScene*))dlsym(api.lib, "jp_upload_scene");
+		api.render = (int (*)(JpContext*, const JpRenderParams*, float*))dlsym(api.lib, "jp_render");
+		api.get_counters = (int (*)(JpContext*, JpCounters*))dlsym(api.lib, "jp_get_counters");
+		if (!api.last_error || !api.create_context || !api.destroy_context || !api.upload_scene || !api.render || !api.get_counters)
+		{ api.error = "libjetpbrt_amd.so lacks a required jp_* symbol"; dlclose(api.lib); api.lib = nullptr; }
+	});
+	return api;
+}
+}
+
+FGpuPathIntegrator::FGpuPathIntegrator(int maxDepth, int deviceId) : maxDepth(maxDepth), deviceId(deviceId) { std::memset(&counters, 0, sizeof(counters)); }
+
+FGpuPathIntegrator::~FGpuPathIntegrator()
+{
+	if (ctx && Api().lib) Api().destroy_context(ctx);
+}
+
+void FGpuPathIntegrator::Render(const FScene* scene, FSampler* sampler, FFilm* film, int /*numthreads*/) const
+{
+	fprintf(stderr, "start rendering ...\n");                             // integrator.cc:44
+	HipApi& api = Api();
+	if (!api.lib) { fprintf(stderr, "FGpuPathIntegrator::Render: HIP library not available (%s); nothing rendered\n", api.error.c_str()); lastStatus = JP_ERR_NO_DEVICE; return; }
+	if (!scene || !sampler || !film) { fprintf(stderr, "FGpuPathIntegrator::Render: null argument\n"); lastStatus = JP_ERR_INVALID_ARGUMENT; return; }
+	if (!ctx) { lastStatus = api.create_context(deviceId, &ctx); if (lastStatus != JP_OK) { fprintf(stderr, "FGpuPathIntegrator::Render: %s\n", api.last_error()); ctx = nullptr; return; } }
+	if (uploaded != scene)
+	{
+		FlatScene flat; std::string err;
+		if (!FlattenScene(*scene, flat, &err)) { fprintf(stderr, "FGpuPathIntegrator::Render: %s\n", err.c_str()); lastStatus = JP_ERR_INVALID_ARGUMENT; return; }
+		lastStatus = api.upload_scene(ctx, &flat.view);
+		if (lastStatus != JP_OK) { fprintf(stderr, "FGpuPathIntegrator::Render: %s\n", api.last_error()); return; }
+		uploaded = scene;
+	}
+	JpRenderParams rp; std::memset(&rp, 0, sizeof(rp));
+	rp.width = film->Width(); rp.height = film->Height();
+	rp.spp = sampler->GetSamplesPerPixel(); rp.max_depth = maxDepth;
+	rp.sampler_mode = JP_SAMPLER_COUNTER; rp.seed = sampler->Seed();
+	rp.band_rows = bandRows; rp.shard_index = shardIndex; rp.shard_count = shardCount;
+	std::vector<float> rgb((size_t)rp.width * rp.height * 3);
+	lastStatus = api.render(ctx, &rp, rgb.data());
+	if (lastStatus != JP_OK) { fprintf(stderr, "FGpuPathIntegrator::Render: %s\n", api.last_error()); return; }
+	for (int y = 0; y < rp.height; y++) for (int x = 0; x < rp.width; x++)
+	{
+		const float* p = &rgb[3 * ((size_t)y * rp.width + x)];
+		film->AddColor(x, y, FColor(p[0], p[1], p[2]));                   // integrator.cc:108 / film.h:64-68
+	}
+	api.get_counters(ctx, &counters);
+	fprintf(stderr, "finish rendering ...\n");
+	fprintf(stderr, "FIntegrator::Render used %f seconds.\n", (float)(counters.render_ms / 1000.0));   // integrator.cc:77-79
+}
+
+} // namespace jetpbrt

@@ -1,0 +1,292 @@
+// jet-pbrt_amd/host/jetpbrt.h -- host-side mirror of the reference's Scene/Camera/Film/Sampler/Material/
+// Integrator API vocabulary (SURVEY.md section 7 "design stance"), written from scratch for the GPU path:
+// objects here only DESCRIBE a scene; nothing in this layer traces a ray.  FScene::Preprocess() builds the
+// BVH, FlattenScene() turns the preprocessed scene into the SoA arrays of include/jetpbrt_amd.h, and
+// FGpuPathIntegrator::Render() -- same signature as FIntegrator::Render (integrator.h:32) -- hands them to
+// the HIP library through the C ABI.
+//
+// Names follow the reference so that code written against it (main.cc:13-111) ports by changing the
+// namespace.  Unlike the reference objects (whose parameters are protected), every
+// object exposes the state the flattener needs.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "jetpbrt_amd.h"
+
+namespace jetpbrt
+{
+typedef float Float;                                             // pbrt.h:27
+constexpr Float kPi = (Float)3.14159265358979323846;             // pbrt.h:39
+
+struct FColor                                                    // color.h:13-69 (data + what the host needs)
+{
+	Float r, g, b;
+	FColor() : r(0), g(0), b(0) {}
+	FColor(Float v) : r(v), g(v), b(v) {}
+	FColor(Float rr, Float gg, Float bb) : r(rr), g(gg), b(bb) {}
+	FColor operator-(const FColor& c) const { return FColor(r - c.r, g - c.g, b - c.b); }
+	Float Luminance() const { return 0.212671f * r + 0.715160f * g + 0.072169f * b; }   // color.h:45-48
+};
+
+struct FVector2 { Float x, y; FVector2() : x(0), y(0) {} FVector2(Float vx, Float vy) : x(vx), y(vy) {} };
+typedef FVector2 FPoint2;
+
+struct FVector3                                                  // geometry.h:65-159
+{
+	Float x, y, z;
+	FVector3() : x(0), y(0), z(0) {}
+	FVector3(Float vx, Float vy, Float vz) : x(vx), y(vy), z(vz) {}
+	FVector3 operator-() const { return FVector3(-x, -y, -z); }
+	FVector3 operator+(const FVector3& v) const { return FVector3(x + v.x, y + v.y, z + v.z); }
+	FVector3 operator-(const FVector3& v) const { return FVector3(x - v.x, y - v.y, z - v.z); }
+	FVector3 operator*(Float s) const { return FVector3(x * s, y * s, z * s); }
+	FVector3 operator/(Float s) const { return FVector3(x / s, y / s, z / s); }
+	Float Length2() const { return x * x + y * y + z * z; }
+	Float Length() const { return std::sqrt(Length2()); }
+	FVector3 Normalize() const { return *this / Length(); }
+	FVector3 Cross(const FVector3& v) const { return FVector3(y * v.z - z * v.y, z * v.x - x * v.z, x * v.y - y * v.x); }
+	Float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+typedef FVector3 FPoint3;
+typedef FVector3 FNormal3;
+inline FVector3 Normalize(const FVector3& v) { return v.Normalize(); }
+inline FVector3 Cross(const FVector3& a, const FVector3& b) { return a.Cross(b); }
+
+// axis-aligned box with the reference's semantics (geometry.h:244-315): needed bit-for-bit because the
+// environment light's worldRadius (light.cc:26-33) is derived from the union of the shape bounds.
+struct FBounds3
+{
+	FPoint3 _min, _max;
+	FBounds3();
+	FBounds3(const FPoint3& p1, const FPoint3& p2);
+	void Expand(const FBounds3& b);
+	FBounds3 Join(const FPoint3& p) const;
+	void CheckThinness(Float thinness = 0.01f);
+	void BoundingSphere(FPoint3& center, Float& radius) const;
+};
+
+// ---- shapes (geometry only; intersection lives on the device) -----------------------------------------------
+class FShape
+{
+public:
+	virtual ~FShape() = default;
+	virtual int Kind() const = 0;                                // JP_SHAPE_*
+	const FBounds3& WorldBounds() const { return worldBox; }
+	FBounds3 worldBox;
+};
+
+class FTriangle : public FShape                                  // shape.h:277-369
+{
+public:
+	FTriangle(const FPoint3& p0, const FPoint3& p1, const FPoint3& p2, bool flip_normal = false);
+	int Kind() const override { return JP_SHAPE_TRIANGLE; }
+	FPoint3 p0, p1, p2; FNormal3 normal;
+};
+
+class FRectangle : public FShape                                 // shape.h:380-472, shape.cc:76-95
+{
+public:
+	FRectangle(const FPoint3& p0, const FPoint3& p1, const FPoint3& p2, const FPoint3& p3, bool flip_normal = false);
+	static FRectangle FromXY(Float x0, Float x1, Float y0, Float y1, Float z, bool flip_normal = false);
+	static FRectangle FromXZ(Float x0, Float x1, Float z0, Float z1, Float y, bool flip_normal = false);
+	static FRectangle FromYZ(Float y0, Float y1, Float z0, Float z1, Float x, bool flip_normal = false);
+	int Kind() const override { return JP_SHAPE_RECTANGLE; }
+	FPoint3 p0, p1, p2, p3; FNormal3 normal;
+};
+
+class FSphere : public FShape                                    // shape.h:476-662
+{
+public:
+	FSphere(const FVector3& center, Float r);
+	int Kind() const override { return JP_SHAPE_SPHERE; }
+	FVector3 center; Float radius;
+};
+
+// triangulated OBJ ingest with the reference's transform order (shape.cc:23-68): z flip, scale, offset
+bool LoadTriangleMesh(const char* filename, std::vector<std::shared_ptr<FTriangle>>& outTriangles, bool flip_normal = false,
+                      bool bFlipHandedness = false, const FVector3& offset = FVector3(0, 0, 0), Float inScale = 1.f);
+
+// ---- materials: parameter holders with a flatten hook -------------------------------------------------------
+class FMaterial
+{
+public:
+	virtual ~FMaterial() {}
+	virtual int Kind() const = 0;                                // JP_MAT_*
+	virtual void Flatten(float out[JP_MAT_PARAM_STRIDE]) const = 0;
+};
+Float RoughnessToAlpha(Float roughness);                         // microfacet.h:85-90
+
+class FMatteMaterial : public FMaterial                          // material.h:27-41
+{ public: FMatteMaterial(const FColor& c) : diffuseColor(c) {} int Kind() const override { return JP_MAT_MATTE; } void Flatten(float*) const override; FColor diffuseColor; };
+class FMirrorMaterial : public FMaterial                         // material.h:45-59
+{ public: FMirrorMaterial(const FColor& c) : specularColor(c) {} int Kind() const override { return JP_MAT_MIRROR; } void Flatten(float*) const override; FColor specularColor; };
+class FGlassMaterial : public FMaterial                          // material.h:63-81
+{ public: FGlassMaterial(Float eta, const FColor& kr = FColor(1, 1, 1), const FColor& kt = FColor(1, 1, 1)) : eta(eta), Kr(kr), Kt(kt) {}
+  int Kind() const override { return JP_MAT_GLASS; } void Flatten(float*) const override; Float eta; FColor Kr, Kt; };
+class FPlasticMaterial : public FMaterial                        // material.h:85-110, material.cc:12-29
+{ public: FPlasticMaterial(const FColor& Kd, const FColor& Ks, Float roughness, bool remapRoughness);
+  int Kind() const override { return JP_MAT_PLASTIC; } void Flatten(float*) const override; FColor Kd, Ks; Float roughness; bool remapRoughness; Float Qd; };
+class FMetalMaterial : public FMaterial                          // material.h:113-137, material.cc:31-43
+{ public: FMetalMaterial(const FColor& eta, const FColor& k, Float ur, Float vr, bool remap) : eta(eta), k(k), uRoughness(ur), vRoughness(vr), remapRoughness(remap) {}
+  int Kind() const override { return JP_MAT_METAL; } void Flatten(float*) const override; FColor eta, k; Float uRoughness, vRoughness; bool remapRoughness; };
+
+// ---- lights -------------------------------------------------------------------------------------------------
+class FScene;
+enum eLightFlags { DeltaPosition = 1, DeltaDirection = 2, AreaLight = 4, InfiniteLight = 8 };   // light.h:16-23
+
+class FLight
+{
+public:
+	virtual ~FLight() {}
+	FLight(int flags) : lightFlags(flags) {}
+	int Flags() const { return lightFlags; }
+	virtual int Kind() const = 0;                                // JP_LIGHT_*
+	virtual void Preprocess(const FScene&) {}
+	int lightFlags;
+};
+class FAreaLight : public FLight                                 // light.h:183-244
+{ public: FAreaLight(const FPoint3&, int, const FColor& radiance, const FShape* shape) : FLight(eLightFlags::AreaLight), radiance(radiance), shape(shape) {}
+  int Kind() const override { return JP_LIGHT_AREA; } FColor radiance; const FShape* shape; };
+class FEnvironmentLight : public FLight                          // light.h:248-311, light.cc:26-33
+{ public: FEnvironmentLight(const FPoint3&, int, const FColor& radiance) : FLight(eLightFlags::InfiniteLight), radiance(radiance), worldRadius(0) {}
+  int Kind() const override { return JP_LIGHT_ENVIRONMENT; } void Preprocess(const FScene& scene) override; FColor radiance; FPoint3 worldCenter; Float worldRadius; };
+
+struct FPrimitive                                                // primitive.h:20-64
+{
+	const FShape* shape; const FMaterial* material; const FAreaLight* arealight;
+	FPrimitive(const FShape* s, const FMaterial* m, const FAreaLight* l) : shape(s), material(m), arealight(l) {}
+};
+
+// ---- sampler / camera / film ----------------------------------------------------------------------------------
+struct FCameraSample { FPoint2 posfilm; };
+
+class FSampler                                                   // sampler.h:64-105 (description only: the draws happen on the device)
+{
+public:
+	virtual ~FSampler() {}
+	FSampler(int spp) : samples_per_pixel(spp) {}
+	virtual std::unique_ptr<FSampler> Clone() = 0;
+	virtual int GetSamplesPerPixel() { return samples_per_pixel; }
+	virtual void SetSamplesPerPixel(int s) { samples_per_pixel = s; }
+	virtual uint32_t Seed() const = 0;
+protected:
+	int samples_per_pixel;
+};
+// The counter stream of include/jp_counter_rng.h.
+class FCounterSampler : public FSampler
+{ public: FCounterSampler(int spp, uint32_t seed = 1234) : FSampler(spp), seed(seed) {} std::unique_ptr<FSampler> Clone() override { return std::make_unique<FCounterSampler>(samples_per_pixel, seed); }
+  uint32_t Seed() const override { return seed; } uint32_t seed; };
+// Drop-in for main.cc:149.  The stock sequential mt19937_64 stream cannot be reproduced in parallel, so a
+// "random sampler" is served by the counter stream with the stock seed 1234 (sampler.h:26): same
+// distribution, different random numbers.
+class FRandomSampler : public FCounterSampler { public: FRandomSampler(int spp) : FCounterSampler(spp, 1234) {} };
+
+class FCamera                                                    // camera.h:32-70
+{
+public:
+	virtual ~FCamera() {}
+	FCamera(const FVector3& ipos, const FVector3& ifront, const FVector3& iup, Float ifov, const FVector2& iresolution);
+	FVector3 pos, front, right, up; FVector2 resolution;
+};
+
+class FFilm                                                      // film.h:27-94 (pixel store only; image writers are out of scope)
+{
+public:
+	FFilm(int w, int h) : width(w), height(h), pixels((size_t)w * h) {}
+	int Width() const { return width; } int Height() const { return height; }
+	FVector2 GetResolution() const { return FVector2((Float)width, (Float)height); }
+	FColor& operator()(int x, int y) { return pixels[(size_t)width * y + x]; }
+	void AddColor(int x, int y, const FColor& c) { FColor& p = (*this)(x, y); p.r += c.r; p.g += c.g; p.b += c.b; }
+	void Clear() { for (auto& p : pixels) p = FColor(); }
+	int width, height; std::vector<FColor> pixels;
+};
+
+// ---- scene ----------------------------------------------------------------------------------------------------
+struct FlatBVH { std::vector<float> bounds; std::vector<int32_t> left, right, prim_index; };
+
+class FScene                                                     // scene.h:23-150, scene.cc
+{
+public:
+	FScene(const char* inName) : name(inName) {}
+	const char* NameStr() const { return name.c_str(); }
+	void Preprocess();                                           // world bound -> light preprocess -> BVH build (scene.cc:11-23)
+	FBounds3 WorldBound() const { return worldBound; }
+	const FCamera* Camera() const { return camera.get(); }
+	int LightNum() const { return (int)lights.size(); }
+
+	template<typename T, typename... U> std::shared_ptr<T> CreateCamera(const U&... args) { auto c = std::make_shared<T>(args...); camera = c; return c; }
+	template<typename T, typename... U> std::shared_ptr<T> CreateShape(const U&... args) { auto s = std::make_shared<T>(args...); shapes.push_back(s); return s; }
+	template<typename T, typename... U> std::shared_ptr<T> CreateMaterial(const U&... args) { auto m = std::make_shared<T>(args...); materials.push_back(m); return m; }
+	template<typename T, typename... U> std::shared_ptr<T> CreateLight(const U&... args) { auto l = std::make_shared<T>(args...); lights.push_back(l); return l; }
+	template<typename... U> std::shared_ptr<FPrimitive> CreatePrimitive(const U&... args) { auto p = std::make_shared<FPrimitive>(args...); primitives.push_back(p); return p; }
+
+	std::vector<std::shared_ptr<FShape>> CreateTriangleMesh(const char* filename, bool flip_normal = false, bool bFlipHandedness = false, const FVector3& offset = FVector3(0, 0, 0), Float inScale = 1.f);
+	std::vector<std::shared_ptr<FPrimitive>> CreatePrimitives(const std::vector<std::shared_ptr<FShape>>& inMesh, const std::shared_ptr<FMaterial>& inMaterial);
+	std::vector<std::shared_ptr<FAreaLight>> CreateAreaLights(int samplesNum, const FColor& radiance, const std::vector<std::shared_ptr<FShape>>& inShapes, const std::shared_ptr<FMaterial>& inMaterial);
+	std::shared_ptr<FAreaLight> CreateAreaLight(int samplesNum, const FColor& radiance, const std::shared_ptr<FShape>& inShape, const std::shared_ptr<FMaterial>& inMaterial);
+
+	std::string name;
+	std::shared_ptr<FCamera> camera;
+	std::vector<std::shared_ptr<FShape>> shapes;
+	std::vector<std::shared_ptr<FMaterial>> materials;
+	std::vector<std::shared_ptr<FLight>> lights;
+	std::vector<std::shared_ptr<FPrimitive>> primitives;
+	FBounds3 worldBound;
+	FlatBVH bvh;                                                 // built by Preprocess()
+	bool preprocessed = false;
+};
+
+// binned-SAH BVH over primitive bounds -> the flat node arrays of JpScene (own topology)
+void BuildBVH(const std::vector<FBounds3>& primBounds, FlatBVH& out, int maxLeaf = 4);
+
+// the flattener: owns the SoA storage a JpScene view points into
+struct FlatScene
+{
+	JpScene view;
+	std::vector<float> tri_p0, tri_p1, tri_p2, tri_n, rect_p0, rect_p1, rect_p2, rect_p3, rect_n, sph_center, sph_radius;
+	std::vector<int32_t> prim_shape_type, prim_shape_index, prim_material, prim_light, mat_type, light_type, light_prim;
+	std::vector<float> mat_params, light_radiance;
+	FlatBVH bvh;
+};
+bool FlattenScene(const FScene& scene, FlatScene& out, std::string* error = nullptr);
+
+// ---- integrator -------------------------------------------------------------------------------------------------
+class FIntegrator
+{
+public:
+	virtual ~FIntegrator() {}
+	// same contract as integrator.h:32 / integrator.cc:35-80: blocking, results ADDED onto `film` (film.h:64-68)
+	virtual void Render(const FScene* scene, FSampler* sampler, FFilm* film, int numthreads = 1) const = 0;
+};
+
+// FPathIntegratorIteration (integrator.h:109-122, integrator.cc:316-403) executed by the HIP wavefront kernels.
+// `numthreads` is accepted for signature compatibility and ignored.  Failures (no GPU, library missing, bad
+// scene) print through PBRT-style stderr logging and leave the film untouched -- the reference's error
+// convention; there is NO CPU fallback.  LastStatus() exposes the JpStatus.
+class FGpuPathIntegrator : public FIntegrator
+{
+public:
+	explicit FGpuPathIntegrator(int maxDepth, int deviceId = 0);
+	~FGpuPathIntegrator();
+	void Render(const FScene* scene, FSampler* sampler, FFilm* film, int numthreads = 1) const override;
+	int LastStatus() const { return lastStatus; }
+	const JpCounters& Counters() const { return counters; }
+	// multi-GPU band sharding (JpRenderParams::shard_*); default renders the whole film
+	void SetShard(int index, int count, int bandRows = 20) { shardIndex = index; shardCount = count; this->bandRows = bandRows; }
+protected:
+	int maxDepth, deviceId;
+	int shardIndex = 0, shardCount = 1, bandRows = 20;
+	mutable JpContext* ctx = nullptr;
+	mutable const FScene* uploaded = nullptr;
+	mutable int lastStatus = 0;
+	mutable JpCounters counters;
+};
+typedef FGpuPathIntegrator FPathIntegratorIteration;             // main.cc:154 compiles unchanged
+
+} // namespace jetpbrt
