@@ -1,0 +1,193 @@
+// jet-pbrt_amd/csrc/jp_device.h -- device-side math, scene tables, BVH traversal and shape intersection.
+//
+// Parity rules (DESIGN.md "Numerics"): everything that restates reference arithmetic is plain fp32 in the
+// reference's operation order; this file is compiled with -ffp-contract=off so no mul+add pair is fused, and
+// fp32 divide / sqrt are the correctly rounded forms (hipcc default).  Only the BVH slab test -- our own
+// topology, conservative by construction -- uses explicit fmaf / min3 / max3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "jetpbrt_amd.h"
+#include "jp_counter_rng.h"
+
+#define JP_BLOCK 256
+#define JP_STACK_DEPTH 32
+
+namespace jp
+{
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ V3 cmul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 cdiv(V3 a, V3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
+__device__ __forceinline__ V3 splat(float v) { return mk(v, v, v); }
+__device__ __forceinline__ V3 csqrt(V3 a) { return mk(sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // geometry.h:107
+__device__ __forceinline__ float len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }               // geometry.h:101
+__device__ __forceinline__ float len(V3 a) { return sqrtf(len2(a)); }                              // geometry.h:102
+__device__ __forceinline__ V3 normalize(V3 a) { return a / len(a); }                                    // geometry.h:104
+__device__ __forceinline__ V3 cross(V3 a, V3 v) { return mk(a.y * v.z - a.z * v.y, a.z * v.x - a.x * v.z, a.x * v.y - a.y * v.x); }
+__device__ __forceinline__ float absdot(V3 a, V3 b) { return fabsf(dot(a, b)); }
+__device__ __forceinline__ bool isblack(V3 c) { return c.x == 0.f && c.y == 0.f && c.z == 0.f; }        // color.h:50
+// std::min / std::max with libstdc++'s argument semantics (NaN-order sensitive)
+__device__ __forceinline__ float smin(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ float maxcomp(V3 c) { float m = (c.y < c.z) ? c.z : c.y; return (c.x < m) ? m : c.x; }   // color.h:40-43
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { if (v < lo) return lo; else if (v > hi) return hi; else return v; }   // pbrt.h:73-83
+__device__ __forceinline__ V3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
+
+#define JP_PI      3.14159274101257324219f          /* (float)3.14159265358979323846, pbrt.h:39 */
+#define JP_INF     __int_as_float(0x7f800000)
+
+// ---- device scene tables ---------------------------------------------------------------------------------------
+// Primitive record, 4 x float4 (64 B), stored in BVH leaf order:
+//   triangle : g0 = (p0, -), g1 = (p1, -), g2 = (p2, -),   g3 = (n, type)
+//   rectangle: g0 = (p0, p3.x), g1 = (p1, p3.y), g2 = (p2, p3.z), g3 = (n, type)
+//   sphere   : g0 = (c, r),                                 g3 = (-, -, -, type)
+// meta = (orig primitive id, material, light, shape type)
+// BVH node, 4 x float4 (64 B): both children's boxes live in the parent so one fetch decides both descents:
+//   n0 = (L.min.xyz, L.max.x)  n1 = (L.max.yz, R.min.xy)  n2 = (R.min.z, R.max.xyz)  n3 = (ref L, ref R, -, -) as int bits
+//   ref >= 0: interior node index; ref < 0: leaf, e = -ref-1, first = e >> 4, count = (e & 15) + 1
+struct SceneView
+{
+	const float4* nodes; int n_nodes;
+	const float4* prims; const int4* meta; int n_prims;
+	const float4* mats;                     // 4 x float4 per material (JP_MAT_PARAM_STRIDE floats)
+	const int* mat_type; int n_mats;
+	const float4* lights;                   // 2 x float4 per light: (radiance, type bits), (device prim bits, inv_area, -, -)
+	int n_lights;
+	float3 env_sum;                         // sum of the infinite lights' radiance in Lights() order (light.h:300-303)
+	int n_env;
+	float world_radius;
+	JpCamera cam;
+};
+
+// ---- shape intersection: exact restatements ---------------------------------------------------------------------
+// FTriangle::Intersect shape.h:291-327.  On acceptance `tmax` shrinks (ray.SetMaxT).
+__device__ __forceinline__ bool tri_hit(V3 p0, V3 p1, V3 p2, V3 n, V3 o, V3 d, float tmin, float& tmax)
+{
+	const V3 oa = p0 - o, ob = p1 - o, oc = p2 - o;
+	const V3 v0 = cross(oc, ob), v1 = cross(ob, oa), v2 = cross(oa, oc);
+	const float v0d = dot(v0, d), v1d = dot(v1, d), v2d = dot(v2, d);
+	if (((v0d < 0) && (v1d < 0) && (v2d < 0)) || ((v0d >= 0) && (v1d >= 0) && (v2d >= 0)))
+	{
+		const float distance = dot(n, oa) / dot(n, d);
+		if ((distance > tmin) && (distance < tmax)) { tmax = distance; return true; }
+	}
+	return false;
+}
+// FRectangle::Intersect shape.h:399-435
+__device__ __forceinline__ bool rect_hit(V3 p0, V3 p1, V3 p2, V3 p3, V3 n, V3 o, V3 d, float tmin, float& tmax)
+{
+	const V3 oa = p0 - o, ob = p1 - o, oc = p2 - o, od = p3 - o;
+	const V3 v0 = cross(oc, ob), v1 = cross(ob, oa), v2 = cross(oa, od), v3 = cross(od, oc);
+	const float v0d = dot(v0, d), v1d = dot(v1, d), v2d = dot(v2, d), v3d = dot(v3, d);
+	if (((v0d < 0) && (v1d < 0) && (v2d < 0) && (v3d < 0)) || ((v0d >= 0) && (v1d >= 0) && (v2d >= 0) && (v3d >= 0)))
+	{
+		const float distance = dot(n, oa) / dot(n, d);
+		if ((distance > tmin) && (distance < tmax)) { tmax = distance; return true; }
+	}
+	return false;
+}
+// FSphere::Intersect shape.h:487-526 (sqrt resolves to the double overload there; for sqrt the double rounding
+// is innocuous, so the correctly rounded fp32 sqrt gives the identical value)
+__device__ __forceinline__ bool sph_hit(V3 c, float r, V3 o, V3 d, float tmin, float& tmax)
+{
+	V3 oc = o - c;
+	float a = len2(d);
+	float half_b = dot(oc, d);
+	float cc = len2(oc) - r * r;
+	float disc = half_b * half_b - a * cc;
+	if (disc > 0.0f)
+	{
+		float root = sqrtf(disc);
+		float time;
+		float root1 = (-half_b - root) / a;
+		if (root1 < tmax && root1 > tmin) time = root1;
+		else
+		{
+			float root2 = (-half_b + root) / a;
+			if (root2 < tmax && root2 > tmin) time = root2;
+			else return false;
+		}
+		tmax = time;
+		return true;
+	}
+	return false;
+}
+
+// One primitive record against the ray; FPrimitive::Intersect primitive.h:39-48.
+template <typename PrimPtr>
+__device__ __forceinline__ bool prim_hit(PrimPtr prims, int pi, V3 o, V3 d, float tmin, float& tmax)
+{
+	const float4 g3 = prims[4 * pi + 3];
+	const int type = __float_as_int(g3.w);
+	const float4 g0 = prims[4 * pi + 0];
+	if (type == JP_SHAPE_SPHERE) return sph_hit(xyz(g0), g0.w, o, d, tmin, tmax);
+	const float4 g1 = prims[4 * pi + 1], g2 = prims[4 * pi + 2];
+	if (type == JP_SHAPE_TRIANGLE) return tri_hit(xyz(g0), xyz(g1), xyz(g2), xyz(g3), o, d, tmin, tmax);
+	return rect_hit(xyz(g0), xyz(g1), xyz(g2), mk(g0.w, g1.w, g2.w), xyz(g3), o, d, tmin, tmax);
+}
+
+// ---- BVH traversal (replaces FBVH_Node::Intersect bvh.h:94-103: ordered, early-out, any-hit for shadows) -------
+// `stack` is this thread's column of the LDS stack: entry k lives at stack[k * JP_BLOCK].
+// Returns the device primitive index of the accepted hit (-1: none); `tmax` holds the hit distance.
+template <bool kAnyHit, typename NodePtr, typename PrimPtr>
+__device__ __forceinline__ int traverse(NodePtr nodes, PrimPtr prims, V3 o, V3 d, float tmin, float& tmax, int* stack)
+{
+	const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+	int hit = -1;
+	int sp = 0;
+	int cur = 0;                                                  // node 0 is the root (always interior on the device)
+	for (;;)
+	{
+		if (cur >= 0)
+		{
+			const float4 n0 = nodes[4 * cur + 0], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
+			// slab test, both children; fminf/fmaxf drop the NaN of 0 * inf (ray in a slab plane)
+			float lx0 = (n0.x - o.x) * ix, lx1 = (n0.w - o.x) * ix;
+			float ly0 = (n0.y - o.y) * iy, ly1 = (n1.x - o.y) * iy;
+			float lz0 = (n0.z - o.z) * iz, lz1 = (n1.y - o.z) * iz;
+			float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), tmin));
+			float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), tmax));
+			float rx0 = (n1.z - o.x) * ix, rx1 = (n2.y - o.x) * ix;
+			float ry0 = (n1.w - o.y) * iy, ry1 = (n2.z - o.y) * iy;
+			float rz0 = (n2.x - o.z) * iz, rz1 = (n2.w - o.z) * iz;
+			float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), tmin));
+			float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), tmax));
+			const bool hl = ln <= lf * 1.0000005f, hr = rn <= rf * 1.0000005f;   // conservative: never culls a true hit
+			const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
+			if (hl && hr)
+			{
+				const bool leftFirst = ln <= rn;
+				cur = leftFirst ? cl : cr;
+				stack[sp * JP_BLOCK] = leftFirst ? cr : cl; sp++;
+				continue;
+			}
+			if (hl) { cur = cl; continue; }
+			if (hr) { cur = cr; continue; }
+		}
+		else
+		{
+			const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
+			for (int k = 0; k < count; k++)
+			{
+				if (prim_hit(prims, first + k, o, d, tmin, tmax))
+				{
+					hit = first + k;
+					if (kAnyHit) return hit;
+				}
+			}
+		}
+		if (sp == 0) break;
+		sp--; cur = stack[sp * JP_BLOCK];
+	}
+	return hit;
+}
+
+} // namespace jp

@@ -1,0 +1,879 @@
+// jet-pbrt_amd/csrc/jp_kernels.hip -- the wavefront path tracer: hand-written gfx950 HIP kernels plus the C ABI
+// of include/jetpbrt_amd.h.  Replaces the per-pixel / per-sample loop of the reference
+// (FIntegrator::Render integrator.cc:35-80 -> DoRender :82-111 -> FPathIntegratorIteration::Li :316-403).
+//
+// One batch = all pixels of this GPU's bands x S samples = P path slots (slot = s_local * NPIX + pixel).
+//   k_raygen   camera samples -> ray queue                         (sampler.h:148-155, camera.h:52-58)
+//   per bounce:
+//   k_extend   closest hit per queued ray: BVH traversal with an LDS stack, scene in LDS when it fits
+//   k_shade    emission, material closure, NEE light samples -> shadow queue, BSDF sample, Russian roulette,
+//              surviving paths compacted into the next ray queue (wave ballots + block prefix + one atomic)
+//   k_shadow   any-hit traversal per shadow entry, visible contributions added to the path's radiance in light order
+//   k_resolve  per pixel: sequential fp32 sum over the batch's samples in index order (integrator.cc:102-105)
+// All queues are SoA float4 arrays in HBM; launches are asynchronous on one stream with no host round trip
+// inside a batch (queue lengths live in device memory, kernels are grid-stride over them).
+#include "jp_shading.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <cmath>
+
+using namespace jp;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// device structures
+// ---------------------------------------------------------------------------------------------------------------------
+struct DevCounters
+{
+	unsigned int n_queue[2];
+	unsigned int n_shadow;
+	unsigned int pad;
+	unsigned long long closest, closest_hit, shadow, shadow_occ;
+};
+
+struct Queues
+{
+	float4 *ray_o[2], *ray_d[2], *beta[2];     // ping-pong ray queues: (o, slot) (d, flags) (beta, key)
+	float2 *hit;                               // (t, device prim index or -1) per queued ray
+	float4 *lacc;                              // per slot: radiance of the path so far
+	float4 *sh_o;                              // per shadow entry: (origin, slot | count << 24)
+	float4 *sh_d, *sh_c;                       // plane k at [k * cap + q]: (dir, tmax), (contribution, -)
+	unsigned int cap;                          // path slots P
+};
+
+struct RenderConst
+{
+	int width, height, spp, max_depth;
+	unsigned int seed;
+	int band_rows, shard_index, shard_count;
+	int npix;            // pixels of this shard
+	int local_rows;
+	int s0, sbatch;      // first sample index and sample count of this batch
+	int n_planes;        // shadow ray planes (lights that can emit)
+};
+
+#define FLAG_BOUNCE(f) ((f) & 0xff)
+#define FLAG_SPEC(f)   (((f) >> 8) & 1)
+#define FLAG_DIM(f)    (((unsigned)(f)) >> 16)
+#define MK_FLAGS(bounce, spec, dim) (((bounce) & 0xff) | ((spec) ? 0x100 : 0) | ((int)(dim) << 16))
+
+__device__ __forceinline__ void pixel_of(const RenderConst& rc, int pix, int& x, int& y)
+{
+	x = pix % rc.width;
+	int r = pix / rc.width;
+	int j = r / rc.band_rows;
+	y = (rc.shard_index + j * rc.shard_count) * rc.band_rows + (r - j * rc.band_rows);
+}
+
+// block-wide allocation of one output slot per flagged thread: wave ballot + popcount prefix, per-wave totals
+// through LDS, ONE atomic per block on the queue counter.  Every thread of the block must call it.
+__device__ __forceinline__ unsigned int block_alloc(bool flag, unsigned int* counter, unsigned int* s_tmp /* [JP_BLOCK/64 + 1] */)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned long long m = __ballot(flag);
+	const unsigned int prefix = __popcll(m & ((1ull << lane) - 1ull));
+	__syncthreads();                                         // s_tmp reuse guard
+	if (lane == 0) s_tmp[wave] = (unsigned int)__popcll(m);
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		unsigned int tot = 0;
+		for (int w = 0; w < JP_BLOCK / 64; w++) { unsigned int t = s_tmp[w]; s_tmp[w] = tot; tot += t; }
+		s_tmp[JP_BLOCK / 64] = tot ? atomicAdd(counter, tot) : 0u;
+	}
+	__syncthreads();
+	return s_tmp[JP_BLOCK / 64] + s_tmp[wave] + prefix;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_raygen: FSampler::GetCameraSample (sampler.h:148-155) + FCamera::GenerateRay (camera.h:52-58)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(JP_BLOCK) k_raygen(SceneView sc, Queues q, RenderConst rc, DevCounters* cnt)
+{
+	const unsigned int total = (unsigned int)rc.npix * rc.sbatch;
+	if (blockIdx.x == 0 && threadIdx.x == 0) { cnt->n_queue[0] = total; cnt->n_queue[1] = 0; cnt->n_shadow = 0; }
+	for (unsigned int slot = blockIdx.x * JP_BLOCK + threadIdx.x; slot < total; slot += gridDim.x * JP_BLOCK)
+	{
+		const int pix = slot % rc.npix, s = rc.s0 + slot / rc.npix;
+		int x, y; pixel_of(rc, pix, x, y);
+		const uint32_t key = jp_rng_key(rc.seed, (uint32_t)x, (uint32_t)y, (uint32_t)s);
+		const float fx = (float)x + jp_rng_float(key, 0), fy = (float)y + jp_rng_float(key, 1);
+		const V3 front = mk(sc.cam.front[0], sc.cam.front[1], sc.cam.front[2]);
+		const V3 right = mk(sc.cam.right[0], sc.cam.right[1], sc.cam.right[2]);
+		const V3 up = mk(sc.cam.up[0], sc.cam.up[1], sc.cam.up[2]);
+		V3 dir = front + right * (fx / sc.cam.res_x - 0.5f) + up * (0.5f - fy / sc.cam.res_y);
+		dir = normalize(dir);
+		q.ray_o[0][slot] = make_float4(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2], __int_as_float((int)slot));
+		q.ray_d[0][slot] = make_float4(dir.x, dir.y, dir.z, __int_as_float(MK_FLAGS(0, 0, 2)));
+		q.beta[0][slot] = make_float4(1.f, 1.f, 1.f, __int_as_float((int)key));
+		q.lacc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// scene staging into LDS for the traversal kernels
+// ---------------------------------------------------------------------------------------------------------------------
+extern __shared__ float4 s_dyn[];      // [stack: depth * JP_BLOCK ints][nodes][prims]   (16-byte aligned base)
+
+template <bool kLds>
+struct SceneAccess;
+template <> struct SceneAccess<false>
+{
+	const float4 *nodes, *prims; int* stack;
+	__device__ __forceinline__ SceneAccess(const SceneView& sc, int depth) : nodes(sc.nodes), prims(sc.prims), stack((int*)s_dyn + threadIdx.x) { (void)depth; }
+};
+template <> struct SceneAccess<true>
+{
+	float4 *nodes, *prims; int* stack;
+	__device__ __forceinline__ SceneAccess(const SceneView& sc, int depth)
+	{
+		stack = (int*)s_dyn + threadIdx.x;
+		nodes = s_dyn + (depth * JP_BLOCK) / 4;
+		prims = nodes + 4 * sc.n_nodes;
+		for (int i = threadIdx.x; i < 4 * sc.n_nodes; i += JP_BLOCK) nodes[i] = sc.nodes[i];
+		for (int i = threadIdx.x; i < 4 * sc.n_prims; i += JP_BLOCK) prims[i] = sc.prims[i];
+		__syncthreads();
+	}
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_extend: FScene::Intersect (scene.cc:25-33) for every queued ray
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool kLds>
+__global__ void __launch_bounds__(JP_BLOCK) k_extend(SceneView sc, Queues q, int cur, int depth, DevCounters* cnt)
+{
+	__shared__ unsigned int s_hits;
+	SceneAccess<kLds> acc(sc, depth);
+	const unsigned int count = cnt->n_queue[cur];
+	if (blockIdx.x == 0 && threadIdx.x == 0) { cnt->n_queue[cur ^ 1] = 0; cnt->n_shadow = 0; cnt->closest += count; }
+	if (threadIdx.x == 0) s_hits = 0;
+	__syncthreads();
+	unsigned int myhits = 0;
+	for (unsigned int i = blockIdx.x * JP_BLOCK + threadIdx.x; i < count; i += gridDim.x * JP_BLOCK)
+	{
+		const float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i];
+		float tmax = JP_INF;
+		const int hit = traverse<false>(acc.nodes, acc.prims, xyz(ro), xyz(rd), 0.001f, tmax, acc.stack);   // FRay defaults geometry.h:399
+		q.hit[i] = make_float2(tmax, __int_as_float(hit));
+		myhits += hit >= 0 ? 1u : 0u;
+	}
+	const unsigned long long m = __ballot(myhits != 0);      // cheap pre-filter, then wave reduction
+	if (m)
+	{
+		for (int off = 32; off > 0; off >>= 1) myhits += __shfl_down(myhits, off);
+		if ((threadIdx.x & 63) == 0) atomicAdd(&s_hits, myhits);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && s_hits) atomicAdd(&cnt->closest_hit, (unsigned long long)s_hits);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_shade: the body of FPathIntegratorIteration::Li after the intersection (integrator.cc:328-399)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, RenderConst rc, int cur, DevCounters* cnt)
+{
+	__shared__ unsigned int s_tmp[JP_BLOCK / 64 + 1];
+	const unsigned int count = cnt->n_queue[cur];
+	const int nxt = cur ^ 1;
+	const unsigned int nloops = (count + gridDim.x * JP_BLOCK - 1) / (gridDim.x * JP_BLOCK);
+	for (unsigned int it = 0; it < nloops; it++)
+	{
+		const unsigned int i = (it * gridDim.x + blockIdx.x) * JP_BLOCK + threadIdx.x;
+		const bool valid = i < count;
+		bool shaded = false, wantNee = false, alive = false;
+		V3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(0, 0, 0), p = mk(0, 0, 0), N = mk(0, 0, 1);
+		int slot = 0, bounce = 0; bool spec = false; unsigned int dim = 0; uint32_t key = 0;
+		Closure c; c.kind = CL_LAMBERT; Frame fr; fr.s = fr.t = fr.n = mk(0, 0, 1);
+		if (valid)
+		{
+			const float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i], rb = q.beta[cur][i];
+			const float2 h = q.hit[i];
+			o = xyz(ro); d = xyz(rd); beta = xyz(rb);
+			slot = __float_as_int(ro.w); key = (uint32_t)__float_as_int(rb.w);
+			const int flags = __float_as_int(rd.w);
+			bounce = FLAG_BOUNCE(flags); spec = FLAG_SPEC(flags); dim = FLAG_DIM(flags);
+			const int pi = __float_as_int(h.y);
+			const bool found = pi >= 0;
+			int mat = -1;
+			V3 Le = splat(0);
+			if (found)
+			{
+				const float4 g3 = sc.prims[4 * pi + 3];
+				const int4 meta = sc.meta[pi];
+				const int type = __float_as_int(g3.w);
+				p = o + h.x * d;                                                      // ray(distance) geometry.h:412-416
+				if (type == JP_SHAPE_TRIANGLE) N = xyz(g3);
+				else if (type == JP_SHAPE_RECTANGLE) N = dot(xyz(g3), d) <= 0 ? xyz(g3) : -xyz(g3);   // shape.h:427
+				else { const float4 g0 = sc.prims[4 * pi]; N = normalize(p - xyz(g0)); }              // shape.h:521
+				mat = meta.y;
+				if (meta.z >= 0 && (bounce == 0 || spec))                             // primitive.h:60-63, light.h:234-238
+				{
+					const V3 wo = -d;
+					if (dot(N, wo) > 0.f) Le = xyz(sc.lights[2 * meta.z]);
+				}
+			}
+			else if (bounce == 0 || spec)                                             // integrator.cc:334-336, light.h:300-303
+			{
+				// L += beta * Le for each infinite light in order; folded on the host only when there is at most one
+				for (int li = 0; li < sc.n_lights; li++)
+				{
+					const float4 l0 = sc.lights[2 * li];
+					if (__float_as_int(l0.w) == JP_LIGHT_ENVIRONMENT && !isblack(xyz(l0)))
+					{
+						float4 L = q.lacc[slot];
+						V3 a = mk(L.x, L.y, L.z) + cmul(beta, xyz(l0));
+						q.lacc[slot] = make_float4(a.x, a.y, a.z, 0.f);
+					}
+				}
+			}
+			if (!isblack(Le))
+			{
+				float4 L = q.lacc[slot];
+				V3 a = mk(L.x, L.y, L.z) + cmul(beta, Le);                            // integrator.cc:331
+				q.lacc[slot] = make_float4(a.x, a.y, a.z, 0.f);
+			}
+			if (found && bounce < rc.max_depth)                                       // integrator.cc:340-343
+			{
+				if (mat < 0) alive = true;                                            // integrator.cc:349-353: pass through, same bounce
+				else
+				{
+					float up = 0.f;
+					if (sc.mat_type[mat] == JP_MAT_PLASTIC) up = jp_rng_float(key, dim++);   // material.cc:14
+					make_closure(sc, mat, up, c);
+					fr = frame_from_z(N);
+					shaded = true;
+					wantNee = !is_delta(c);
+				}
+			}
+		}
+		// ---- next-event estimation: one shadow entry per non-delta shaded path (integrator.cc:357-372) ----
+		const unsigned int qs = block_alloc(wantNee, &cnt->n_shadow, s_tmp);
+		V3 nd = d, nbeta = beta; int nbounce = bounce; bool nspec = spec;
+		if (shaded)
+		{
+			const V3 wo_w = -d;
+			const V3 wo = to_local(fr, wo_w);
+			if (wantNee)
+			{
+				int k = 0;
+				for (int li = 0; li < sc.n_lights; li++)
+				{
+					const float ux = jp_rng_float(key, dim), uy = jp_rng_float(key, dim + 1); dim += 2;
+					LightSample ls = sample_li(sc, sc.prims, li, p, N, ux, uy);
+					if (isblack(ls.Li) || ls.pdf == 0.f) continue;
+					const V3 f = eval_local(c, wo, to_local(fr, ls.wi));               // FBSDF::Evalf bsdf.h:284-287
+					if (isblack(f)) continue;
+					// FScene::Occluded scene.h:36-47: dir and distance recomputed from the sampled position
+					const V3 sdir = normalize(ls.pos - p);
+					const float dist = len(p - ls.pos);
+					const V3 contrib = cmul(cmul(beta, f), ls.Li) * absdot(ls.wi, N) / ls.pdf;   // integrator.cc:369
+					if (k < rc.n_planes)
+					{
+						q.sh_d[(size_t)k * q.cap + qs] = make_float4(sdir.x, sdir.y, sdir.z, dist - 0.001f);
+						q.sh_c[(size_t)k * q.cap + qs] = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
+						k++;
+					}
+				}
+				q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
+			}
+			// ---- BSDF sample (integrator.cc:375-379) ----
+			const float ux = jp_rng_float(key, dim), uy = jp_rng_float(key, dim + 1); dim += 2;
+			BsdfSample bs = sample_local(c, wo, ux, uy);
+			bs.wi = to_world(fr, bs.wi);                                              // bsdf.h:295-301
+			if (!(isblack(bs.f) || bs.pdf == 0.f))
+			{
+				nspec = (bs.flags & BS_SPECULAR) != 0;                                // integrator.cc:381
+				if (bounce >= 3)                                                      // integrator.cc:383-393
+				{
+					const float qq = smax(0.05f, 1 - maxcomp(bs.f));
+					const float ur = jp_rng_float(key, dim++);
+					if (!(ur < qq))
+					{
+						nbeta = cmul(beta, bs.f * absdot(bs.wi, N) / (bs.pdf * (1 - qq)));
+						alive = true;
+					}
+				}
+				else
+				{
+					nbeta = cmul(beta, bs.f * absdot(bs.wi, N) / bs.pdf);             // integrator.cc:397
+					alive = true;
+				}
+				nd = bs.wi; nbounce = bounce + 1;
+			}
+		}
+		// ---- compact survivors into the next ray queue ----
+		const unsigned int j = block_alloc(alive, &cnt->n_queue[nxt], s_tmp);
+		if (alive)
+		{
+			q.ray_o[nxt][j] = make_float4(p.x, p.y, p.z, __int_as_float(slot));       // SpawnRay shape.h:61-64
+			q.ray_d[nxt][j] = make_float4(nd.x, nd.y, nd.z, __int_as_float(MK_FLAGS(nbounce, nspec, dim)));
+			q.beta[nxt][j] = make_float4(nbeta.x, nbeta.y, nbeta.z, __int_as_float((int)key));
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_shadow: FScene::Occluded (scene.h:36-47) for the entry's rays in light order; L += contribution when visible
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool kLds>
+__global__ void __launch_bounds__(JP_BLOCK) k_shadow(SceneView sc, Queues q, int depth, DevCounters* cnt)
+{
+	__shared__ unsigned int s_rays, s_occ;
+	SceneAccess<kLds> acc(sc, depth);
+	const unsigned int count = cnt->n_shadow;
+	if (threadIdx.x == 0) { s_rays = 0; s_occ = 0; }
+	__syncthreads();
+	unsigned int rays = 0, occ = 0;
+	for (unsigned int e = blockIdx.x * JP_BLOCK + threadIdx.x; e < count; e += gridDim.x * JP_BLOCK)
+	{
+		const float4 so = q.sh_o[e];
+		const int packed = __float_as_int(so.w);
+		const int slot = packed & 0xffffff, n = (packed >> 24) & 0xff;
+		if (n == 0) continue;
+		V3 add = mk(0, 0, 0); bool any = false;
+		float4 L = q.lacc[slot];
+		V3 a = mk(L.x, L.y, L.z);
+		for (int k = 0; k < n; k++)
+		{
+			const float4 sd = q.sh_d[(size_t)k * q.cap + e];
+			float tmax = sd.w;
+			const int hit = traverse<true>(acc.nodes, acc.prims, xyz(so), xyz(sd), 0.001f, tmax, acc.stack);
+			rays++;
+			if (hit >= 0) occ++;
+			else { const float4 sc4 = q.sh_c[(size_t)k * q.cap + e]; a = a + xyz(sc4); any = true; }
+		}
+		(void)add;
+		if (any) q.lacc[slot] = make_float4(a.x, a.y, a.z, 0.f);
+	}
+	for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); occ += __shfl_down(occ, off); }
+	if ((threadIdx.x & 63) == 0) { if (rays) atomicAdd(&s_rays, rays); if (occ) atomicAdd(&s_occ, occ); }
+	__syncthreads();
+	if (threadIdx.x == 0) { if (s_rays) atomicAdd(&cnt->shadow, (unsigned long long)s_rays); if (s_occ) atomicAdd(&cnt->shadow_occ, (unsigned long long)s_occ); }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_resolve: the per-pixel sample loop's sum (integrator.cc:89,102-108) in sample-index order; the running sum of a
+// pixel lives in pix_acc across batches; the last batch writes Clamp01 onto the (zero) film.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(JP_BLOCK) k_resolve(Queues q, RenderConst rc, float4* pix_acc, float* film, int first, int last)
+{
+	const float ratio = 1.0f / (float)rc.spp;
+	for (int pix = blockIdx.x * JP_BLOCK + threadIdx.x; pix < rc.npix; pix += gridDim.x * JP_BLOCK)
+	{
+		V3 L = mk(0, 0, 0);
+		if (!first) { const float4 a = pix_acc[pix]; L = mk(a.x, a.y, a.z); }
+		for (int s = 0; s < rc.sbatch; s++)
+		{
+			const float4 l = q.lacc[(size_t)s * rc.npix + pix];
+			L = L + mk(l.x, l.y, l.z) * ratio;
+		}
+		if (!last) pix_acc[pix] = make_float4(L.x, L.y, L.z, 0.f);
+		else
+		{
+			int x, y; pixel_of(rc, pix, x, y);
+			float* o = film + 3 * ((size_t)y * rc.width + x);
+			o[0] = 0.f + clampf(L.x, 0.f, 1.f); o[1] = 0.f + clampf(L.y, 0.f, 1.f); o[2] = 0.f + clampf(L.z, 0.f, 1.f);   // film.h:22-23, 64-68
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_trace: test hook, arbitrary rays through the same traversal
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool kLds>
+__global__ void __launch_bounds__(JP_BLOCK) k_trace(SceneView sc, int depth, int n, const float* o, const float* d, const float* tmin, const float* tmax_in,
+                                                    int* hit, float* t, int* prim, float* nrm)
+{
+	SceneAccess<kLds> acc(sc, depth);
+	for (int i = blockIdx.x * JP_BLOCK + threadIdx.x; i < n; i += gridDim.x * JP_BLOCK)
+	{
+		const V3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+		float tmax = tmax_in[i];
+		const int h = traverse<false>(acc.nodes, acc.prims, ro, rd, tmin[i], tmax, acc.stack);
+		hit[i] = h >= 0; t[i] = tmax; prim[i] = h >= 0 ? sc.meta[h].x : -1;
+		V3 N = mk(0, 0, 0);
+		if (h >= 0)
+		{
+			const float4 g3 = sc.prims[4 * h + 3]; const int type = __float_as_int(g3.w);
+			const V3 p = ro + tmax * rd;
+			if (type == JP_SHAPE_TRIANGLE) N = xyz(g3);
+			else if (type == JP_SHAPE_RECTANGLE) N = dot(xyz(g3), rd) <= 0 ? xyz(g3) : -xyz(g3);
+			else N = normalize(p - xyz(sc.prims[4 * h]));
+		}
+		nrm[3 * i] = N.x; nrm[3 * i + 1] = N.y; nrm[3 * i + 2] = N.z;
+	}
+}
+
+// =====================================================================================================================
+// host side: context, scene upload, render loop, C ABI
+// =====================================================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(JP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+
+struct JpContext
+{
+	int device = 0;
+	hipStream_t stream = nullptr;
+	int n_cus = 256;
+	// scene
+	bool have_scene = false;
+	SceneView sv; int stack_depth = 1; bool scene_in_lds = false; size_t lds_bytes = 0;
+	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr;
+	int n_planes = 1; bool has_null_material = false;
+	// queues
+	Queues q; unsigned int cap = 0; int planes_alloc = 0;
+	std::vector<void*> qbufs;
+	float4* d_pix_acc = nullptr; size_t pix_acc_n = 0;
+	float* d_film = nullptr; size_t film_n = 0;
+	DevCounters* d_cnt = nullptr;
+	// timing
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	bool profiling = false;
+	std::vector<hipEvent_t> evpool; size_t evused = 0;
+	struct Stamp { int cls; size_t a, b; };
+	std::vector<Stamp> stamps;
+	JpCounters counters;
+};
+
+static void free_scene(JpContext* c)
+{
+	void** ps[] = { &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights };
+	for (void** p : ps) { if (*p) hipFree(*p); *p = nullptr; }
+	c->have_scene = false;
+}
+static void free_queues(JpContext* c)
+{
+	for (void* p : c->qbufs) hipFree(p);
+	c->qbufs.clear(); c->cap = 0; c->planes_alloc = 0;
+}
+
+extern "C" {
+
+const char* jp_last_error(void) { return g_err.c_str(); }
+int jp_abi_version(void) { return JP_ABI_VERSION; }
+
+int jp_create_context(int device_id, JpContext** out)
+{
+	if (!out) return fail(JP_ERR_INVALID_ARGUMENT, "jp_create_context: out is null");
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(JP_ERR_NO_DEVICE, "jp_create_context: no HIP device visible (this library has no CPU fallback)");
+	if (device_id < 0 || device_id >= n) return fail(JP_ERR_NO_DEVICE, "jp_create_context: device id out of range");
+	HIP_TRY(hipSetDevice(device_id));
+	JpContext* c = new JpContext;
+	c->device = device_id;
+	std::memset(&c->counters, 0, sizeof(c->counters));
+	std::memset(&c->q, 0, sizeof(c->q));
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount;
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess
+	    || hipMalloc((void**)&c->d_cnt, sizeof(DevCounters)) != hipSuccess)
+	{ delete c; return fail(JP_ERR_DEVICE, "jp_create_context: stream/event/counter allocation failed"); }
+	*out = c;
+	return JP_OK;
+}
+
+int jp_destroy_context(JpContext* c)
+{
+	if (!c) return JP_OK;
+	hipSetDevice(c->device);
+	if (c->stream) hipStreamSynchronize(c->stream);
+	free_scene(c); free_queues(c);
+	if (c->d_pix_acc) hipFree(c->d_pix_acc);
+	if (c->d_film) hipFree(c->d_film);
+	if (c->d_cnt) hipFree(c->d_cnt);
+	for (hipEvent_t e : c->evpool) hipEventDestroy(e);
+	if (c->ev0) hipEventDestroy(c->ev0);
+	if (c->ev1) hipEventDestroy(c->ev1);
+	if (c->stream) hipStreamDestroy(c->stream);
+	delete c;
+	return JP_OK;
+}
+
+} // extern "C"
+
+// ---- scene validation + upload ----------------------------------------------------------------------------------------
+namespace
+{
+struct HV3 { float x, y, z; };
+inline HV3 hsub(HV3 a, HV3 b) { HV3 r = { a.x - b.x, a.y - b.y, a.z - b.z }; return r; }
+inline HV3 hcross(HV3 a, HV3 v) { HV3 r = { a.y * v.z - a.z * v.y, a.z * v.x - a.x * v.z, a.x * v.y - a.y * v.x }; return r; }
+inline float hlen(HV3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+inline HV3 hld(const float* p) { HV3 r = { p[0], p[1], p[2] }; return r; }
+
+int bvh_height(const JpScene* s, int node, int depth, int limit, bool& bad, std::vector<char>& seen)
+{
+	if (node < 0 || node >= s->n_bvh_nodes || seen[node] || depth > limit) { bad = true; return 0; }
+	seen[node] = 1;
+	if (s->bvh_left[node] < 0) return 0;                               // leaf
+	int a = bvh_height(s, s->bvh_left[node], depth + 1, limit, bad, seen);
+	int b = bvh_height(s, s->bvh_right[node], depth + 1, limit, bad, seen);
+	return 1 + std::max(a, b);
+}
+}
+
+extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
+{
+	if (!c || !s) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: null argument");
+	// ---- validate every index on the host: a bad index must never reach a kernel ----
+	if (s->n_primitives <= 0) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: scene has no primitives");
+	if (s->n_triangles < 0 || s->n_rectangles < 0 || s->n_spheres < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_bvh_nodes <= 0 || s->n_bvh_prim_indices < 0)
+		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: negative count");
+	if (!s->prim_shape_type || !s->prim_shape_index || !s->prim_material || !s->prim_light || !s->bvh_bounds || !s->bvh_left || !s->bvh_right || !s->bvh_prim_index)
+		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: null array");
+	if ((s->n_triangles && (!s->tri_p0 || !s->tri_p1 || !s->tri_p2 || !s->tri_n)) || (s->n_rectangles && (!s->rect_p0 || !s->rect_p1 || !s->rect_p2 || !s->rect_p3 || !s->rect_n))
+	    || (s->n_spheres && (!s->sph_center || !s->sph_radius)) || (s->n_materials && (!s->mat_type || !s->mat_params)) || (s->n_lights && (!s->light_type || !s->light_radiance || !s->light_prim)))
+		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: null array for a non-zero count");
+	if (s->n_lights > 255) return fail(JP_ERR_UNSUPPORTED, "jp_upload_scene: more than 255 lights are not supported by the shadow-entry packing");
+	bool hasNull = false;
+	for (int i = 0; i < s->n_primitives; i++)
+	{
+		int t = s->prim_shape_type[i], k = s->prim_shape_index[i];
+		int lim = t == JP_SHAPE_TRIANGLE ? s->n_triangles : t == JP_SHAPE_RECTANGLE ? s->n_rectangles : t == JP_SHAPE_SPHERE ? s->n_spheres : -1;
+		if (lim < 0 || k < 0 || k >= lim) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: primitive shape reference out of range");
+		if (s->prim_material[i] < -1 || s->prim_material[i] >= s->n_materials) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: primitive material out of range");
+		if (s->prim_light[i] < -1 || s->prim_light[i] >= s->n_lights) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: primitive light out of range");
+		if (s->prim_light[i] >= 0 && s->light_type[s->prim_light[i]] != JP_LIGHT_AREA) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: primitive light is not an area light");
+		if (s->prim_material[i] < 0) hasNull = true;
+	}
+	for (int i = 0; i < s->n_materials; i++) if (s->mat_type[i] < JP_MAT_MATTE || s->mat_type[i] > JP_MAT_METAL) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: unknown material type");
+	for (int i = 0; i < s->n_lights; i++)
+	{
+		if (s->light_type[i] == JP_LIGHT_AREA) { if (s->light_prim[i] < 0 || s->light_prim[i] >= s->n_primitives) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: area light primitive out of range"); }
+		else if (s->light_type[i] != JP_LIGHT_ENVIRONMENT) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: unknown light type");
+	}
+	// BVH: a tree, every primitive in exactly one leaf, leaf ranges in bounds, height within the LDS stack
+	std::vector<char> seen(s->n_bvh_nodes, 0); bool bad = false;
+	int height = bvh_height(s, 0, 0, 4 * JP_STACK_DEPTH, bad, seen);
+	if (bad) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: BVH is not a tree rooted at node 0 (cycle, bad child index or excessive depth)");
+	if (height + 1 > JP_STACK_DEPTH) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: BVH height exceeds the device traversal stack (32)");
+	std::vector<int> primSeen(s->n_primitives, 0);
+	for (int n = 0; n < s->n_bvh_nodes; n++)
+	{
+		if (!seen[n]) continue;
+		if (s->bvh_left[n] >= 0) continue;
+		int first = -s->bvh_left[n] - 1, cnt = s->bvh_right[n];
+		if (cnt < 1 || cnt > 16 || first < 0 || first + cnt > s->n_bvh_prim_indices) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: BVH leaf range invalid (1..16 primitives per leaf)");
+		for (int k = 0; k < cnt; k++) { int p = s->bvh_prim_index[first + k]; if (p < 0 || p >= s->n_primitives) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: BVH primitive index out of range"); primSeen[p]++; }
+	}
+	for (int i = 0; i < s->n_primitives; i++) if (primSeen[i] != 1) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: every primitive must be in exactly one BVH leaf");
+
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	free_scene(c);
+
+	// ---- device primitive records in leaf order + device BVH (children boxes in the parent) ----
+	std::vector<int> hostToDevNode(s->n_bvh_nodes, -1), devPrimOf(s->n_primitives, -1);
+	std::vector<float4> nodes; std::vector<float4> prims; std::vector<int4> meta;
+	auto pad_box = [&](int n, float* b) {
+		for (int a = 0; a < 3; a++)
+		{
+			float lo = s->bvh_bounds[6 * n + a], hi = s->bvh_bounds[6 * n + 3 + a];
+			float m = std::max(std::fabs(lo), std::fabs(hi)); float e = m * 4e-7f + 1e-6f;
+			b[a] = lo - e; b[3 + a] = hi + e;
+		}
+	};
+	auto emit_leaf = [&](int n) -> int {
+		int first = -s->bvh_left[n] - 1, cnt = s->bvh_right[n];
+		int dfirst = (int)meta.size();
+		for (int k = 0; k < cnt; k++)
+		{
+			int p = s->bvh_prim_index[first + k]; devPrimOf[p] = (int)meta.size();
+			int t = s->prim_shape_type[p], i = s->prim_shape_index[p];
+			float4 g[4] = { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) };
+			if (t == JP_SHAPE_TRIANGLE)
+			{
+				g[0] = make_float4(s->tri_p0[3 * i], s->tri_p0[3 * i + 1], s->tri_p0[3 * i + 2], 0); g[1] = make_float4(s->tri_p1[3 * i], s->tri_p1[3 * i + 1], s->tri_p1[3 * i + 2], 0);
+				g[2] = make_float4(s->tri_p2[3 * i], s->tri_p2[3 * i + 1], s->tri_p2[3 * i + 2], 0); g[3] = make_float4(s->tri_n[3 * i], s->tri_n[3 * i + 1], s->tri_n[3 * i + 2], 0);
+			}
+			else if (t == JP_SHAPE_RECTANGLE)
+			{
+				g[0] = make_float4(s->rect_p0[3 * i], s->rect_p0[3 * i + 1], s->rect_p0[3 * i + 2], s->rect_p3[3 * i]);
+				g[1] = make_float4(s->rect_p1[3 * i], s->rect_p1[3 * i + 1], s->rect_p1[3 * i + 2], s->rect_p3[3 * i + 1]);
+				g[2] = make_float4(s->rect_p2[3 * i], s->rect_p2[3 * i + 1], s->rect_p2[3 * i + 2], s->rect_p3[3 * i + 2]);
+				g[3] = make_float4(s->rect_n[3 * i], s->rect_n[3 * i + 1], s->rect_n[3 * i + 2], 0);
+			}
+			else g[0] = make_float4(s->sph_center[3 * i], s->sph_center[3 * i + 1], s->sph_center[3 * i + 2], s->sph_radius[i]);
+			int tb = t; std::memcpy(&g[3].w, &tb, 4);
+			for (int j = 0; j < 4; j++) prims.push_back(g[j]);
+			int4 m; m.x = p; m.y = s->prim_material[p]; m.z = s->prim_light[p]; m.w = t; meta.push_back(m);
+		}
+		return -(((dfirst << 4) | (cnt - 1)) + 1);
+	};
+	// interior nodes get device indices in DFS order
+	std::vector<int> order; { std::vector<int> st; st.push_back(0); while (!st.empty()) { int n = st.back(); st.pop_back(); if (s->bvh_left[n] < 0) continue; hostToDevNode[n] = (int)order.size(); order.push_back(n); st.push_back(s->bvh_right[n]); st.push_back(s->bvh_left[n]); } }
+	const float kEmpty[6] = { 1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f };
+	if (order.empty())
+	{   // the root itself is a leaf: a synthetic interior root whose right child can never be hit
+		float lb[6]; pad_box(0, lb);
+		int ref = emit_leaf(0), rr = ref; float fr, fl; std::memcpy(&fl, &ref, 4); std::memcpy(&fr, &rr, 4);
+		nodes.push_back(make_float4(lb[0], lb[1], lb[2], lb[3])); nodes.push_back(make_float4(lb[4], lb[5], kEmpty[0], kEmpty[1]));
+		nodes.push_back(make_float4(kEmpty[2], kEmpty[3], kEmpty[4], kEmpty[5])); nodes.push_back(make_float4(fl, fr, 0, 0));
+	}
+	else
+	{
+		nodes.resize(4 * order.size());
+		for (size_t di = 0; di < order.size(); di++)
+		{
+			int n = order[di], l = s->bvh_left[n], r = s->bvh_right[n];
+			float lb[6], rb[6]; pad_box(l, lb); pad_box(r, rb);
+			int lref = s->bvh_left[l] < 0 ? emit_leaf(l) : hostToDevNode[l];
+			int rref = s->bvh_left[r] < 0 ? emit_leaf(r) : hostToDevNode[r];
+			float fl, fr; std::memcpy(&fl, &lref, 4); std::memcpy(&fr, &rref, 4);
+			nodes[4 * di + 0] = make_float4(lb[0], lb[1], lb[2], lb[3]); nodes[4 * di + 1] = make_float4(lb[4], lb[5], rb[0], rb[1]);
+			nodes[4 * di + 2] = make_float4(rb[2], rb[3], rb[4], rb[5]); nodes[4 * di + 3] = make_float4(fl, fr, 0, 0);
+		}
+	}
+	if (meta.size() >= (1u << 27)) return fail(JP_ERR_UNSUPPORTED, "jp_upload_scene: too many primitives for the leaf reference encoding");
+
+	// materials: the 16-float rows as 4 x float4
+	std::vector<float4> mats(4 * std::max(1, s->n_materials)); std::vector<int> mtype(std::max(1, s->n_materials), 0);
+	for (int i = 0; i < s->n_materials; i++) { std::memcpy(&mats[4 * i], s->mat_params + (size_t)i * JP_MAT_PARAM_STRIDE, 16 * sizeof(float)); mtype[i] = s->mat_type[i]; }
+	// lights: (radiance, type) (device prim, 1/Area(), -, -); areas with the reference's expressions (shape.h:351, 457, 546)
+	std::vector<float4> lights(2 * std::max(1, s->n_lights)); int planes = 0, nenv = 0; float envsum[3] = { 0, 0, 0 };
+	for (int i = 0; i < s->n_lights; i++)
+	{
+		int ty = s->light_type[i]; float tf; std::memcpy(&tf, &ty, 4);
+		const float* rad = s->light_radiance + 3 * i;
+		lights[2 * i] = make_float4(rad[0], rad[1], rad[2], tf);
+		bool black = rad[0] == 0.f && rad[1] == 0.f && rad[2] == 0.f;
+		if (!black) planes++;
+		float inv_area = 0.f; int dp = -1;
+		if (ty == JP_LIGHT_AREA)
+		{
+			int p = s->light_prim[i]; dp = devPrimOf[p];
+			int t = s->prim_shape_type[p], k = s->prim_shape_index[p]; float area;
+			if (t == JP_SHAPE_TRIANGLE) area = 0.5f * hlen(hcross(hsub(hld(s->tri_p1 + 3 * k), hld(s->tri_p0 + 3 * k)), hsub(hld(s->tri_p2 + 3 * k), hld(s->tri_p0 + 3 * k))));
+			else if (t == JP_SHAPE_RECTANGLE) area = hlen(hcross(hsub(hld(s->rect_p0 + 3 * k), hld(s->rect_p1 + 3 * k)), hsub(hld(s->rect_p2 + 3 * k), hld(s->rect_p1 + 3 * k))));
+			else { const float kPi = (float)3.14159265358979323846; float r2 = s->sph_radius[k] * s->sph_radius[k]; area = 4 * kPi * r2; }
+			inv_area = 1 / area;
+		}
+		else { nenv++; envsum[0] += rad[0]; envsum[1] += rad[1]; envsum[2] += rad[2]; }
+		float df; std::memcpy(&df, &dp, 4);
+		lights[2 * i + 1] = make_float4(df, inv_area, 0, 0);
+	}
+	// meta.z must index lights (already does); fix nothing else.
+
+	auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+		hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16)); if (e != hipSuccess) return e;
+		return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+	};
+	HIP_TRY(up(&c->d_nodes, nodes.data(), nodes.size() * sizeof(float4)));
+	HIP_TRY(up(&c->d_prims, prims.data(), prims.size() * sizeof(float4)));
+	HIP_TRY(up(&c->d_meta, meta.data(), meta.size() * sizeof(int4)));
+	HIP_TRY(up(&c->d_mats, mats.data(), mats.size() * sizeof(float4)));
+	HIP_TRY(up(&c->d_mat_type, mtype.data(), mtype.size() * sizeof(int)));
+	HIP_TRY(up(&c->d_lights, lights.data(), lights.size() * sizeof(float4)));
+
+	SceneView& v = c->sv;
+	v.nodes = (const float4*)c->d_nodes; v.n_nodes = (int)nodes.size() / 4;
+	v.prims = (const float4*)c->d_prims; v.meta = (const int4*)c->d_meta; v.n_prims = (int)meta.size();
+	v.mats = (const float4*)c->d_mats; v.mat_type = (const int*)c->d_mat_type; v.n_mats = s->n_materials;
+	v.lights = (const float4*)c->d_lights; v.n_lights = s->n_lights;
+	v.env_sum = make_float3(envsum[0], envsum[1], envsum[2]); v.n_env = nenv;
+	v.world_radius = s->world_radius; v.cam = s->camera;
+	c->stack_depth = std::max(2, height + 2);
+	size_t scene_bytes = (nodes.size() + prims.size()) * sizeof(float4);
+	size_t stack_bytes = (size_t)c->stack_depth * JP_BLOCK * sizeof(int);
+	c->scene_in_lds = scene_bytes + stack_bytes <= 48 * 1024;
+	c->lds_bytes = stack_bytes + (c->scene_in_lds ? scene_bytes : 0);
+	c->n_planes = std::max(1, planes);
+	c->has_null_material = hasNull;
+	c->have_scene = true;
+	return JP_OK;
+}
+
+// ---- render ---------------------------------------------------------------------------------------------------------------
+namespace
+{
+enum { CLS_EXTEND = 0, CLS_SHADE = 1, CLS_SHADOW = 2, CLS_OTHER = 3 };
+
+int ensure_queues(JpContext* c, unsigned int cap, int planes)
+{
+	if (c->cap >= cap && c->planes_alloc >= planes) return JP_OK;
+	free_queues(c);
+	auto alloc = [&](void** p, size_t bytes) -> bool { if (hipMalloc(p, bytes) != hipSuccess) return false; c->qbufs.push_back(*p); return true; };
+	Queues& q = c->q; bool ok = true;
+	for (int b = 0; b < 2 && ok; b++) ok = alloc((void**)&q.ray_o[b], (size_t)cap * 16) && alloc((void**)&q.ray_d[b], (size_t)cap * 16) && alloc((void**)&q.beta[b], (size_t)cap * 16);
+	ok = ok && alloc((void**)&q.hit, (size_t)cap * 8) && alloc((void**)&q.lacc, (size_t)cap * 16) && alloc((void**)&q.sh_o, (size_t)cap * 16)
+	     && alloc((void**)&q.sh_d, (size_t)cap * 16 * planes) && alloc((void**)&q.sh_c, (size_t)cap * 16 * planes);
+	if (!ok) { free_queues(c); return fail(JP_ERR_DEVICE, "jp_render: out of device memory for the path queues"); }
+	q.cap = cap; c->cap = cap; c->planes_alloc = planes;
+	return JP_OK;
+}
+
+struct Stamper
+{
+	JpContext* c; int cls; size_t a;
+	Stamper(JpContext* c, int cls) : c(c), cls(cls), a(0)
+	{
+		if (!c->profiling) return;
+		if (c->evused + 2 > c->evpool.size()) { size_t old = c->evpool.size(); c->evpool.resize(old + 64); for (size_t i = old; i < c->evpool.size(); i++) hipEventCreate(&c->evpool[i]); }
+		a = c->evused; c->evused += 2;
+		hipEventRecord(c->evpool[a], c->stream);
+	}
+	~Stamper() { if (!c->profiling) return; hipEventRecord(c->evpool[a + 1], c->stream); JpContext::Stamp s = { cls, a, a + 1 }; c->stamps.push_back(s); }
+};
+
+int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sync)
+{
+	if (!c || !rp || !film_dev) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: null argument");
+	if (!c->have_scene) return fail(JP_ERR_NO_SCENE, "jp_render: no scene uploaded");
+	if (rp->width <= 0 || rp->height <= 0 || rp->spp <= 0 || rp->max_depth < 0 || rp->max_depth > 200) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: bad width/height/spp/max_depth");
+	if (rp->sampler_mode != JP_SAMPLER_COUNTER) return fail(JP_ERR_UNSUPPORTED, "jp_render: the device path implements the counter sampler only (the sequential mt19937_64 stream is not reproducible in parallel)");
+	const int band = rp->band_rows > 0 ? rp->band_rows : 20;
+	const int scount = rp->shard_count > 1 ? rp->shard_count : 1;
+	const int sidx = scount > 1 ? rp->shard_index : 0;
+	if (sidx < 0 || sidx >= scount) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: shard_index out of range");
+	HIP_TRY(hipSetDevice(c->device));
+
+	const int nbands = (rp->height + band - 1) / band;
+	int local_rows = 0;
+	for (int b = sidx; b < nbands; b += scount) local_rows += std::min(band, rp->height - b * band);
+	const long long npix = (long long)local_rows * rp->width;
+
+	HIP_TRY(hipEventRecord(c->ev0, c->stream));
+	HIP_TRY(hipMemsetAsync(film_dev, 0, sizeof(float) * 3 * (size_t)rp->width * rp->height, c->stream));
+	HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(DevCounters), c->stream));
+	c->evused = 0; c->stamps.clear();
+	unsigned long long samples = 0;
+	if (npix > 0)
+	{
+		if (npix > (1 << 24)) return fail(JP_ERR_UNSUPPORTED, "jp_render: more than 2^24 pixels per shard");
+		const unsigned int PMAX = 1u << 24;                          // slot index is packed in 24 bits
+		// memory budget for the queues: ~ (120 + 32 * planes) bytes per slot
+		size_t freeB = 0, totalB = 0; hipMemGetInfo(&freeB, &totalB);
+		size_t per = 136 + 32 * (size_t)c->n_planes;
+		size_t budget = std::min<size_t>((size_t)24 << 30, (freeB + (c->cap ? (size_t)c->cap * (136 + 32 * (size_t)c->planes_alloc) : 0)) / 2);
+		unsigned int pcap = (unsigned int)std::min<size_t>(PMAX, std::max<size_t>((size_t)npix, budget / per));
+		int sbatch = (int)std::max<long long>(1, std::min<long long>(rp->spp, pcap / npix));
+		if ((long long)sbatch * npix > (long long)PMAX) return fail(JP_ERR_UNSUPPORTED, "jp_render: shard too large for one batch");
+		unsigned int cap = (unsigned int)((long long)sbatch * npix);
+		int st = ensure_queues(c, cap, c->n_planes); if (st != JP_OK) return st;
+		if (c->pix_acc_n < (size_t)npix) { if (c->d_pix_acc) hipFree(c->d_pix_acc); c->d_pix_acc = nullptr; HIP_TRY(hipMalloc((void**)&c->d_pix_acc, (size_t)npix * 16)); c->pix_acc_n = (size_t)npix; }
+
+		RenderConst rc; rc.width = rp->width; rc.height = rp->height; rc.spp = rp->spp; rc.max_depth = rp->max_depth; rc.seed = rp->seed;
+		rc.band_rows = band; rc.shard_index = sidx; rc.shard_count = scount; rc.npix = (int)npix; rc.local_rows = local_rows; rc.n_planes = c->planes_alloc < c->n_planes ? c->planes_alloc : c->n_planes;
+		const int grid = c->n_cus * 8;
+		const size_t lds = c->lds_bytes;
+		for (int s0 = 0; s0 < rp->spp; s0 += sbatch)
+		{
+			rc.s0 = s0; rc.sbatch = std::min(sbatch, rp->spp - s0);
+			{ Stamper t(c, CLS_OTHER); hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(JP_BLOCK), 0, c->stream, c->sv, c->q, rc, c->d_cnt); }
+			int cur = 0;
+			int iters = rp->max_depth + 1;
+			for (int it = 0;; it++)
+			{
+				if (it >= iters)
+				{
+					if (!c->has_null_material || it > iters + 64) break;
+					// null-material primitives re-queue a path without consuming a bounce (integrator.cc:349-353): ask the device
+					DevCounters h; HIP_TRY(hipMemcpyAsync(&h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream));
+					if (h.n_queue[cur] == 0) break;
+				}
+				{
+					Stamper t(c, CLS_EXTEND);
+					if (c->scene_in_lds) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
+					else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
+				}
+				{ Stamper t(c, CLS_SHADE); hipLaunchKernelGGL(k_shade, dim3(grid), dim3(JP_BLOCK), 0, c->stream, c->sv, c->q, rc, cur, c->d_cnt); }
+				{
+					Stamper t(c, CLS_SHADOW);
+					if (c->scene_in_lds) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, c->stack_depth, c->d_cnt);
+					else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, c->stack_depth, c->d_cnt);
+				}
+				cur ^= 1;
+			}
+			{ Stamper t(c, CLS_OTHER); hipLaunchKernelGGL(k_resolve, dim3((unsigned int)std::min<long long>(grid, (npix + JP_BLOCK - 1) / JP_BLOCK)), dim3(JP_BLOCK), 0, c->stream, c->q, rc, c->d_pix_acc, film_dev, s0 == 0 ? 1 : 0, s0 + rc.sbatch >= rp->spp ? 1 : 0); }
+			samples += (unsigned long long)rc.sbatch * (unsigned long long)npix;
+		}
+		HIP_TRY(hipGetLastError());
+	}
+	HIP_TRY(hipEventRecord(c->ev1, c->stream));
+	c->counters.samples = samples;
+	if (sync)
+	{
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	return JP_OK;
+}
+
+int finish_counters(JpContext* c)
+{
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	DevCounters h; HIP_TRY(hipMemcpy(&h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost));
+	float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) ms = 0.f;
+	JpCounters& o = c->counters;
+	o.closest_rays = h.closest; o.closest_hits = h.closest_hit; o.shadow_rays = h.shadow; o.shadow_occluded = h.shadow_occ; o.render_ms = ms;
+	o.extend_ms = o.shade_ms = o.shadow_ms = o.other_ms = 0; o.extend_launches = o.shade_launches = o.shadow_launches = 0;
+	for (const JpContext::Stamp& s : c->stamps)
+	{
+		float t = 0.f; if (hipEventElapsedTime(&t, c->evpool[s.a], c->evpool[s.b]) != hipSuccess) continue;
+		if (s.cls == CLS_EXTEND) { o.extend_ms += t; o.extend_launches++; }
+		else if (s.cls == CLS_SHADE) { o.shade_ms += t; o.shade_launches++; }
+		else if (s.cls == CLS_SHADOW) { o.shadow_ms += t; o.shadow_launches++; }
+		else o.other_ms += t;
+	}
+	return JP_OK;
+}
+}
+
+extern "C" {
+
+int jp_render_device(JpContext* c, const JpRenderParams* rp, void* film_rgb_device, int sync) { return render_impl(c, rp, (float*)film_rgb_device, sync != 0); }
+
+int jp_render(JpContext* c, const JpRenderParams* rp, float* film_host)
+{
+	if (!c || !rp || !film_host) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: null argument");
+	if (rp->width <= 0 || rp->height <= 0) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: bad width/height");
+	HIP_TRY(hipSetDevice(c->device));
+	size_t n = (size_t)rp->width * rp->height * 3;
+	if (c->film_n < n) { if (c->d_film) hipFree(c->d_film); c->d_film = nullptr; HIP_TRY(hipMalloc((void**)&c->d_film, n * sizeof(float))); c->film_n = n; }
+	int st = render_impl(c, rp, c->d_film, false); if (st != JP_OK) return st;
+	HIP_TRY(hipMemcpyAsync(film_host, c->d_film, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return JP_OK;
+}
+
+int jp_synchronize(JpContext* c) { if (!c) return fail(JP_ERR_INVALID_ARGUMENT, "jp_synchronize: null context"); HIP_TRY(hipSetDevice(c->device)); HIP_TRY(hipStreamSynchronize(c->stream)); return JP_OK; }
+int jp_set_profiling(JpContext* c, int enabled) { if (!c) return fail(JP_ERR_INVALID_ARGUMENT, "jp_set_profiling: null context"); c->profiling = enabled != 0; return JP_OK; }
+int jp_get_counters(JpContext* c, JpCounters* out)
+{
+	if (!c || !out) return fail(JP_ERR_INVALID_ARGUMENT, "jp_get_counters: null argument");
+	int st = finish_counters(c); if (st != JP_OK) return st;
+	*out = c->counters; return JP_OK;
+}
+
+int jp_trace(JpContext* c, int32_t n, const float* origin, const float* dir, const float* tmin, const float* tmax, int32_t* hit, float* t, int32_t* prim, float* normal)
+{
+	if (!c || n < 0 || !origin || !dir || !tmin || !tmax || !hit || !t || !prim || !normal) return fail(JP_ERR_INVALID_ARGUMENT, "jp_trace: null argument");
+	if (!c->have_scene) return fail(JP_ERR_NO_SCENE, "jp_trace: no scene uploaded");
+	if (n == 0) return JP_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	float *d_o = nullptr, *d_d = nullptr, *d_t0 = nullptr, *d_t1 = nullptr, *d_t = nullptr, *d_n = nullptr; int *d_hit = nullptr, *d_prim = nullptr;
+	int rc = JP_OK;
+	do
+	{
+		if (hipMalloc((void**)&d_o, (size_t)n * 12) != hipSuccess || hipMalloc((void**)&d_d, (size_t)n * 12) != hipSuccess || hipMalloc((void**)&d_t0, (size_t)n * 4) != hipSuccess
+		    || hipMalloc((void**)&d_t1, (size_t)n * 4) != hipSuccess || hipMalloc((void**)&d_t, (size_t)n * 4) != hipSuccess || hipMalloc((void**)&d_n, (size_t)n * 12) != hipSuccess
+		    || hipMalloc((void**)&d_hit, (size_t)n * 4) != hipSuccess || hipMalloc((void**)&d_prim, (size_t)n * 4) != hipSuccess) { rc = fail(JP_ERR_DEVICE, "jp_trace: out of device memory"); break; }
+		hipMemcpyAsync(d_o, origin, (size_t)n * 12, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(d_d, dir, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
+		hipMemcpyAsync(d_t0, tmin, (size_t)n * 4, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(d_t1, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+		int grid = std::min(c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK);
+		if (c->scene_in_lds) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
+		else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
+		hipMemcpyAsync(hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream); hipMemcpyAsync(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+		hipMemcpyAsync(prim, d_prim, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream); hipMemcpyAsync(normal, d_n, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream);
+		hipError_t e = hipStreamSynchronize(c->stream);
+		if (e != hipSuccess) rc = fail(JP_ERR_DEVICE, std::string("jp_trace: ") + hipGetErrorString(e));
+	} while (0);
+	hipFree(d_o); hipFree(d_d); hipFree(d_t0); hipFree(d_t1); hipFree(d_t); hipFree(d_n); hipFree(d_hit); hipFree(d_prim);
+	return rc;
+}
+
+} // extern "C"

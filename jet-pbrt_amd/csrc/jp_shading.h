@@ -1,0 +1,389 @@
+// jet-pbrt_amd/csrc/jp_shading.h -- device restatement of the reference's appearance code: shading frame,
+// BSDF closures (bsdf.h, bsdf.cc, microfacet.cc), material dispatch (material.h/.cc), light sampling (light.h,
+// shape.h sampling) and the sampling warps (sampling.h).  Same operation order as the reference throughout;
+// see jp_device.h for the numerics rules.
+//
+// Transcendentals: the reference calls glibc sinf/cosf (results within ~0.56 ulp, not bit-reproducible across
+// hosts).  The device evaluates sin/cos in fp64 and rounds once to fp32 -- the correctly rounded value in all
+// but ~1e-8 of cases, which coincides with glibc's result wherever glibc is correctly rounded.
+#pragma once
+#include "jp_device.h"
+
+namespace jp
+{
+__device__ __forceinline__ float sin_f(float x) { return (float)sin((double)x); }
+__device__ __forceinline__ float cos_f(float x) { return (float)cos((double)x); }
+
+#define JP_2PI      (2.0f * JP_PI)
+#define JP_PI_OVER2 (JP_PI / 2.0f)
+#define JP_PI_OVER4 (JP_PI / 4.0f)
+#define JP_INV_PI   (1.0f / JP_PI)
+
+enum { BS_REFLECTION = 1, BS_TRANSMISSION = 2, BS_SPECULAR = 4, BS_DIFFUSE = 8, BS_GLOSSY = 16 };   // bsdf.h:208-219
+enum { CL_LAMBERT = 0, CL_MIRROR = 1, CL_FRESNEL_SPECULAR = 2, CL_MICROFACET = 3 };
+enum { FR_CONDUCTOR = 0, FR_DIELECTRIC = 1 };
+
+struct Frame { V3 s, t, n; };
+__device__ __forceinline__ Frame frame_from_z(V3 nn)                                    // geometry.h:345-349, 371-376
+{
+	Frame f; f.n = normalize(nn);
+	V3 tmp = (fabsf(f.n.x) > 0.99f) ? mk(0, 1, 0) : mk(1, 0, 0);
+	f.t = normalize(cross(f.n, tmp));
+	f.s = normalize(cross(f.t, f.n));
+	return f;
+}
+__device__ __forceinline__ V3 to_local(const Frame& f, V3 w) { return mk(dot(f.s, w), dot(f.t, w), dot(f.n, w)); }
+__device__ __forceinline__ V3 to_world(const Frame& f, V3 l) { return f.s * l.x + f.t * l.y + f.n * l.z; }
+
+struct Closure
+{
+	int kind;
+	V3 c0, c1;              // lambert albedo / mirror reflectance / glass Kr,Kt / microfacet R
+	float eta_t;            // glass (eta_i = 1)
+	float ax, ay;           // TrowbridgeReitz alphas
+	int fresnel; V3 feta, fk;
+};
+__device__ __forceinline__ bool is_delta(const Closure& c) { return c.kind == CL_MIRROR || c.kind == CL_FRESNEL_SPECULAR; }
+
+struct BsdfSample { V3 f, wi; float pdf; int flags; };
+
+// ---- sampling warps (sampling.h) ---------------------------------------------------------------------------------
+__device__ __forceinline__ V3 cosine_hemisphere(float ux, float uy)                     // sampling.h:25-59
+{
+	ux = ux * 2.f - 1.f; uy = uy * 2.f - 1.f;
+	float px, py;
+	if (ux == 0 && uy == 0) { px = 0; py = 0; }
+	else
+	{
+		float radius, theta;
+		if (fabsf(ux) > fabsf(uy)) { radius = ux; theta = JP_PI_OVER4 * (uy / ux); }
+		else { radius = uy; theta = JP_PI_OVER2 - JP_PI_OVER4 * (ux / uy); }
+		px = cos_f(theta) * radius; py = sin_f(theta) * radius;
+	}
+	float z = sqrtf(smax(0.f, 1 - px * px - py * py));
+	return mk(px, py, z);
+}
+__device__ __forceinline__ V3 uniform_sphere(float ux, float uy)                        // sampling.h:80-87
+{
+	float z = 1 - 2 * ux;
+	float radius = sqrtf(smax(0.f, 1.f - z * z));
+	float phi = 2 * JP_PI * uy;
+	return mk(radius * cos_f(phi), radius * sin_f(phi), z);
+}
+
+// ---- local-frame helpers (bsdf.h:17-60) ------------------------------------------------------------------------------
+__device__ __forceinline__ bool same_hemi(V3 a, V3 b) { return a.z * b.z > 0; }
+__device__ __forceinline__ float sin2t(V3 w) { return smax(0.f, 1.f - w.z * w.z); }
+__device__ __forceinline__ float sint(V3 w) { return sqrtf(sin2t(w)); }
+__device__ __forceinline__ float tant(V3 w) { return sint(w) / w.z; }
+__device__ __forceinline__ float tan2t(V3 w) { return sin2t(w) / (w.z * w.z); }
+__device__ __forceinline__ float cosphi(V3 w) { float s = sint(w); return (s == 0) ? 1 : clampf(w.x / s, -1.f, 1.f); }
+__device__ __forceinline__ float sinphi(V3 w) { float s = sint(w); return (s == 0) ? 0 : clampf(w.y / s, -1.f, 1.f); }
+
+__device__ __forceinline__ float fresnel_dielectric(float cos_i, float eta_i, float eta_t)     // bsdf.h:91-122
+{
+	cos_i = clampf(cos_i, -1.f, 1.f);
+	bool entering = cos_i > 0.f;
+	if (!entering) { float t = eta_i; eta_i = eta_t; eta_t = t; cos_i = fabsf(cos_i); }
+	float sin_i = sqrtf(smax(0.f, 1 - cos_i * cos_i));
+	float sin_t = eta_i / eta_t * sin_i;
+	if (sin_t >= 1) return 1;
+	float cos_t = sqrtf(smax(0.f, 1 - sin_t * sin_t));
+	float r_para = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+	float r_perp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+	return (r_para * r_para + r_perp * r_perp) / 2;
+}
+
+__device__ __forceinline__ V3 fresnel_conductor(float cosI, V3 etai, V3 etat, V3 k)           // bsdf.h:174-197
+{
+	cosI = clampf(cosI, -1.f, 1.f);
+	V3 eta = cdiv(etat, etai), etak = cdiv(k, etai);
+	float cos2 = cosI * cosI, sin2 = 1 - cos2;
+	V3 eta2 = cmul(eta, eta), etak2 = cmul(etak, etak);
+	V3 t0 = eta2 - etak2 - splat(sin2);
+	V3 a2plusb2 = csqrt(cmul(t0, t0) + cmul(eta2 * 4.f, etak2));
+	V3 t1 = a2plusb2 + splat(cos2);
+	V3 a = csqrt((a2plusb2 + t0) * 0.5f);
+	V3 t2 = a * (2.f * cosI);
+	V3 Rs = cdiv(t1 - t2, t1 + t2);
+	V3 t3 = a2plusb2 * cos2 + splat(sin2 * sin2);
+	V3 t4 = t2 * sin2;
+	V3 Rp = cdiv(cmul(Rs, t3 - t4), t3 + t4);
+	return (Rp + Rs) * 0.5f;
+}
+
+__device__ __forceinline__ V3 fresnel_eval(const Closure& c, float cosI)                      // bsdf.cc:15-24
+{
+	if (c.fresnel == FR_CONDUCTOR) return fresnel_conductor(fabsf(cosI), splat(1.f), c.feta, c.fk);
+	return splat(fresnel_dielectric(cosI, 1.5f, 1.f));                                        // material.cc:21
+}
+
+// TrowbridgeReitzDistribution: microfacet.cc:181-189 (D), 202-210 (Lambda), microfacet.h:22-30 (G1, G), microfacet.cc:359-365 (Pdf)
+__device__ __forceinline__ float tr_D(const Closure& c, V3 wh)
+{
+	float t2 = tan2t(wh);
+	if (isinf(t2)) return 0.f;
+	const float cos4 = (wh.z * wh.z) * (wh.z * wh.z);
+	float cp = cosphi(wh), sp = sinphi(wh);
+	float e = (cp * cp / (c.ax * c.ax) + sp * sp / (c.ay * c.ay)) * t2;
+	return 1 / (JP_PI * c.ax * c.ay * cos4 * (1 + e) * (1 + e));
+}
+__device__ __forceinline__ float tr_Lambda(const Closure& c, V3 w)
+{
+	float absTan = fabsf(tant(w));
+	if (isinf(absTan)) return 0.f;
+	float cp = cosphi(w), sp = sinphi(w);
+	float alpha = sqrtf(cp * cp * c.ax * c.ax + sp * sp * c.ay * c.ay);
+	float a2t2 = (alpha * absTan) * (alpha * absTan);
+	return (-1 + sqrtf(1.f + a2t2)) / 2;
+}
+__device__ __forceinline__ float tr_G1(const Closure& c, V3 w) { return 1 / (1 + tr_Lambda(c, w)); }
+__device__ __forceinline__ float tr_G(const Closure& c, V3 wo, V3 wi) { return 1 / (1 + tr_Lambda(c, wo) + tr_Lambda(c, wi)); }
+__device__ __forceinline__ float tr_Pdf(const Closure& c, V3 wo, V3 wh) { return tr_D(c, wh) * tr_G1(c, wo) * absdot(wo, wh) / fabsf(wo.z); }
+
+// microfacet.cc:256-301; the double-precision spots of the reference (`> .9999`, unqualified sqrt/cos/sin, `> 1e10`) kept
+__device__ __forceinline__ void tr_sample11(float cosTheta, float U1, float U2, float* slope_x, float* slope_y)
+{
+	if ((double)cosTheta > .9999)
+	{
+		float r = sqrtf(U1 / (1 - U1));                     // double sqrt of an fp32 value, rounded back: same value
+		float phi = 6.28318530718f * U2;
+		*slope_x = (float)((double)r * cos((double)phi));
+		*slope_y = (float)((double)r * sin((double)phi));
+		return;
+	}
+	float sinTheta = sqrtf(smax(0.f, 1.f - cosTheta * cosTheta));
+	float tanTheta = sinTheta / cosTheta;
+	float a = 1 / tanTheta;
+	float G1 = 2 / (1 + sqrtf(1.f + 1.f / (a * a)));
+	float A = 2 * U1 / G1 - 1;
+	float tmp = 1.f / (A * A - 1.f);
+	if ((double)tmp > 1e10) tmp = (float)1e10;
+	float B = tanTheta;
+	float D = sqrtf(smax(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.f));
+	float sx1 = B * tmp - D, sx2 = B * tmp + D;
+	*slope_x = (A < 0 || sx2 > 1.f / tanTheta) ? sx1 : sx2;
+	float S;
+	if (U2 > 0.5f) { S = 1.f; U2 = 2.f * (U2 - .5f); }
+	else { S = -1.f; U2 = 2.f * (.5f - U2); }
+	float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) / (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+	*slope_y = S * z * sqrtf(1.f + *slope_x * *slope_x);
+}
+__device__ __forceinline__ V3 tr_sample_wh(const Closure& c, V3 wo, float u0, float u1)       // microfacet.cc:303-357
+{
+	bool flip = wo.z < 0;
+	V3 wi = flip ? -wo : wo;
+	V3 ws = normalize(mk(c.ax * wi.x, c.ay * wi.y, wi.z));
+	float sx, sy; tr_sample11(ws.z, u0, u1, &sx, &sy);
+	float cp = cosphi(ws), sp = sinphi(ws);
+	float tmp = cp * sx - sp * sy;
+	sy = sp * sx + cp * sy;
+	sx = tmp;
+	sx = c.ax * sx; sy = c.ay * sy;
+	V3 wh = normalize(mk(-sx, -sy, 1.f));
+	if (flip) wh = -wh;
+	return wh;
+}
+
+__device__ __forceinline__ V3 eval_local(const Closure& c, V3 wo, V3 wi)
+{
+	if (c.kind == CL_LAMBERT)                                                                 // bsdf.h:347-355
+	{
+		if (!same_hemi(wo, wi)) return splat(0);
+		return c.c0 * JP_INV_PI;
+	}
+	if (c.kind == CL_MICROFACET)                                                              // bsdf.cc:35-51
+	{
+		float cosO = fabsf(wo.z), cosI = fabsf(wi.z);
+		V3 wh = wi + wo;
+		if (cosI == 0 || cosO == 0) return splat(0);
+		if (wh.x == 0 && wh.y == 0 && wh.z == 0) return splat(0);
+		wh = normalize(wh);
+		V3 ff = (dot(wh, mk(0, 0, 1)) < 0) ? -wh : wh;
+		V3 F = fresnel_eval(c, dot(wi, ff));
+		return cmul(c.c0 * tr_D(c, wh) * tr_G(c, wo, wi), F) / (4 * cosI * cosO);
+	}
+	return splat(0);                                                                          // delta BSDFs
+}
+
+__device__ __forceinline__ BsdfSample sample_local(const Closure& c, V3 wo, float ux, float uy)
+{
+	BsdfSample s; s.f = splat(0); s.wi = mk(0, 0, 1); s.pdf = 0; s.flags = 0;                // bsdf.h:252-265
+	if (c.kind == CL_LAMBERT)                                                                 // bsdf.h:362-377
+	{
+		s.wi = cosine_hemisphere(ux, uy);
+		if (wo.z < 0) s.wi.z *= -1;
+		s.f = eval_local(c, wo, s.wi);
+		s.pdf = same_hemi(wo, s.wi) ? fabsf(s.wi.z) * JP_INV_PI : 0;
+		s.flags = BS_REFLECTION | BS_DIFFUSE;
+	}
+	else if (c.kind == CL_MIRROR)                                                             // bsdf.h:415-429
+	{
+		s.wi = mk(-wo.x, -wo.y, wo.z);
+		s.f = c.c0 / fabsf(s.wi.z);
+		s.pdf = 1;
+		s.flags = BS_REFLECTION | BS_SPECULAR;
+	}
+	else if (c.kind == CL_FRESNEL_SPECULAR)                                                   // bsdf.h:478-539
+	{
+		if (wo.z == 0.f) return s;
+		float F = fresnel_dielectric(wo.z, 1.f, c.eta_t);
+		if (ux < F)
+		{
+			s.wi = mk(-wo.x, -wo.y, wo.z);
+			s.pdf = F;
+			s.f = (c.c0 * F) / fabsf(s.wi.z);
+			s.flags = BS_REFLECTION | BS_SPECULAR;
+		}
+		else
+		{
+			bool entering = wo.z > 0;
+			V3 n = entering ? mk(0, 0, 1) : mk(-0.f, -0.f, -1);
+			float etaI = entering ? 1.f : c.eta_t;
+			float etaT = entering ? c.eta_t : 1.f;
+			float eta = etaI / etaT;
+			// refract bsdf.h:70-88
+			float cos_i = dot(n, wo);
+			float sin2_i = smax(0.f, 1 - cos_i * cos_i);
+			float sin2_t = eta * eta * sin2_i;
+			if (sin2_t >= 1) { s.f = splat(0); }
+			else
+			{
+				float cos_t = sqrtf(1 - sin2_t);
+				s.wi = eta * -wo + (eta * cos_i - cos_t) * n;
+				V3 ft = c.c1 * (1 - F);
+				ft = ft * ((etaI * etaI) / (etaT * etaT));
+				s.pdf = 1 - F;
+				s.f = ft / fabsf(s.wi.z);
+				s.flags = BS_TRANSMISSION | BS_SPECULAR;
+			}
+		}
+	}
+	else                                                                                      // bsdf.cc:60-78
+	{
+		if (wo.z == 0) return s;
+		V3 wh = tr_sample_wh(c, wo, ux, uy);
+		float owh = dot(wo, wh);
+		if (owh < 0) return s;
+		V3 wi = -wo + 2 * owh * wh;                                                           // reflect bsdf.h:62-67
+		if (!same_hemi(wo, wi)) return s;
+		s.wi = wi;
+		s.f = eval_local(c, wo, wi);
+		s.pdf = tr_Pdf(c, wo, wh) / (4 * dot(wo, wh));
+		s.flags = BS_REFLECTION | BS_GLOSSY;
+	}
+	return s;
+}
+
+// FMaterial::Scattering (material.h:34-37, 52-55, 72-75; material.cc:12-43).  `uplastic` is the draw
+// FPlasticMaterial consumes (material.cc:14); the caller draws it only for JP_MAT_PLASTIC.
+__device__ __forceinline__ void make_closure(const SceneView& sc, int mat, float uplastic, Closure& c)
+{
+	const int type = sc.mat_type[mat];
+	const float4 p0 = sc.mats[4 * mat + 0], p1 = sc.mats[4 * mat + 1];
+	c.c0 = splat(0); c.c1 = splat(0); c.eta_t = 1; c.ax = c.ay = 0; c.fresnel = FR_CONDUCTOR; c.feta = splat(0); c.fk = splat(0);
+	if (type == JP_MAT_MATTE) { c.kind = CL_LAMBERT; c.c0 = xyz(p0); }
+	else if (type == JP_MAT_MIRROR) { c.kind = CL_MIRROR; c.c0 = xyz(p0); }
+	else if (type == JP_MAT_GLASS) { c.kind = CL_FRESNEL_SPECULAR; c.eta_t = p0.x; c.c0 = mk(p0.y, p0.z, p0.w); c.c1 = mk(p1.x, p1.y, p1.z); }
+	else if (type == JP_MAT_PLASTIC)
+	{
+		float Qd = p1.w;
+		if (uplastic < Qd) { c.kind = CL_LAMBERT; c.c0 = xyz(p0) / Qd; }
+		else { c.kind = CL_MICROFACET; c.c0 = mk(p0.w, p1.x, p1.y) / (1 - Qd); c.fresnel = FR_DIELECTRIC; c.ax = c.ay = smax(0.001f, p1.z); }
+	}
+	else { c.kind = CL_MICROFACET; c.c0 = splat(1.f); c.fresnel = FR_CONDUCTOR; c.feta = xyz(p0); c.fk = mk(p0.w, p1.x, p1.y); c.ax = smax(0.001f, p1.z); c.ay = smax(0.001f, p1.w); }
+}
+
+// ---- lights ---------------------------------------------------------------------------------------------------------
+struct LightSample { V3 pos, wi; float pdf; V3 Li; };
+
+// FLight::Sample_Li for light `li` from surface point p with normal n (isect.normal, used by the sphere's
+// inside branch only).  light.h:199-216 (area), :265-291 (environment); shape sampling shape.h:124-145, 353-363,
+// 459-467, 549-644.
+template <typename PrimPtr>
+__device__ __forceinline__ LightSample sample_li(const SceneView& sc, PrimPtr prims, int li, V3 p, V3 n_isect, float ux, float uy)
+{
+	LightSample s; s.pos = mk(0, 0, 0); s.wi = mk(0, 0, 0); s.pdf = 0; s.Li = splat(0);
+	const float4 l0 = sc.lights[2 * li], l1 = sc.lights[2 * li + 1];
+	const V3 radiance = xyz(l0);
+	if (__float_as_int(l0.w) == JP_LIGHT_ENVIRONMENT)
+	{
+		float theta = uy * JP_PI, phi = ux * 2 * JP_PI;
+		float cosT = cos_f(theta), sinT = sin_f(theta);
+		float sinP = sin_f(phi), cosP = cos_f(phi);
+		s.wi = mk(sinT * cosP, sinT * sinP, cosT);
+		s.pos = p + s.wi * 2 * sc.world_radius;
+		if (sinT != 0) s.pdf = 1 / (2 * JP_PI * JP_PI * sinT);
+		s.Li = radiance;
+		return s;
+	}
+	const int pi = __float_as_int(l1.x);
+	const float inv_area = l1.y;                                  // 1 / FShape::Area(), precomputed at upload with the reference's expression
+	const float4 g0 = prims[4 * pi + 0], g3 = prims[4 * pi + 3];
+	const int type = __float_as_int(g3.w);
+	V3 lp, ln; float pdf;
+	if (type != JP_SHAPE_SPHERE)
+	{
+		const float4 g1 = prims[4 * pi + 1], g2 = prims[4 * pi + 2];
+		if (type == JP_SHAPE_TRIANGLE)                            // shape.h:353-363 + sampling.h:121-125
+		{
+			float su0 = sqrtf(ux); float bx = 1 - su0, by = uy * su0;
+			lp = bx * xyz(g0) + by * xyz(g1) + (1 - bx - by) * xyz(g2);
+		}
+		else lp = xyz(g1) + (xyz(g0) - xyz(g1)) * ux + (xyz(g2) - xyz(g1)) * uy;   // shape.h:459-467
+		ln = xyz(g3);
+		pdf = inv_area;
+		V3 wi = lp - p;                                           // FShape::SampleDirection shape.h:124-145
+		float dist2 = len2(wi);
+		if (dist2 == 0) pdf = 0;
+		else
+		{
+			wi = normalize(wi);
+			pdf *= dist2 / absdot(ln, -wi);
+			if (isinf(pdf)) pdf = 0;
+		}
+	}
+	else
+	{
+		const V3 c = xyz(g0); const float r = g0.w;
+		if (len2(p - c) <= r * r)                                 // shape.h:567-586
+		{
+			V3 dir = uniform_sphere(ux, uy);
+			lp = c + r * dir; ln = normalize(dir);
+			pdf = inv_area;
+			V3 wi = lp - p;
+			if (len2(wi) == 0) pdf = 0;
+			else { wi = normalize(wi); pdf *= len2(lp - p) / absdot(n_isect, -wi); }
+			if (isinf(pdf)) pdf = 0;
+		}
+		else                                                      // shape.h:603-643 cone sampling
+		{
+			float dist = len(p - c);
+			float inv_dist = 1 / dist;
+			float sin_max = r * inv_dist;
+			float sin_max2 = sin_max * sin_max;
+			float inv_sin_max = 1 / sin_max;
+			float cos_max = sqrtf(smax(0.f, 1 - sin_max2));
+			float cos_theta = (cos_max - 1) * ux + 1;
+			float sin_theta2 = 1 - cos_theta * cos_theta;
+			if (sin_max2 < 0.00068523f) { sin_theta2 = sin_max2 * ux; cos_theta = sqrtf(1 - sin_theta2); }
+			float cos_alpha = sin_theta2 * inv_sin_max + cos_theta * sqrtf(smax(0.f, 1.f - sin_theta2 * inv_sin_max * inv_sin_max));
+			float sin_alpha = sqrtf(smax(0.f, 1.f - cos_alpha * cos_alpha));
+			float phi = uy * 2 * JP_PI;
+			Frame fr = frame_from_z((c - p) * inv_dist);
+			V3 wn = sin_alpha * cos_f(phi) * (-fr.s) + sin_alpha * sin_f(phi) * (-fr.t) + cos_alpha * (-fr.n);
+			lp = c + r * wn; ln = wn;
+			pdf = 1 / (2 * JP_PI * (1 - cos_max));
+		}
+	}
+	s.pos = lp; s.pdf = pdf;
+	if (pdf == 0 || len2(lp - p) == 0) s.Li = splat(0);           // light.h:205-214
+	else
+	{
+		s.wi = normalize(lp - p);
+		s.Li = (dot(ln, -s.wi) > 0.f) ? radiance : splat(0);      // FAreaLight::L light.h:234-238
+	}
+	return s;
+}
+
+} // namespace jp
