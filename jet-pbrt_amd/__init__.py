@@ -182,3 +182,4 @@ class Context:
 
 
 from . import scenes  # noqa: E402,F401
+from . import distributed  # noqa: E402,F401

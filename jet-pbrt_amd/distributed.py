@@ -1,0 +1,29 @@
+"""Multi-GPU plumbing: one process per GPU, 20-row bands of the film dealt round-robin to the ranks, one
+reduce(sum) of the per-rank films onto rank 0 (RCCL over xGMI on the GPU box; gloo in the CPU tests).
+
+The path shards by pixels with no data-path exchange: a rank's film is zero outside its
+bands, so the sum over ranks is the disjoint union and -- with the counter sampler -- bit-identical to the
+single-rank film.  `render_fn(params) -> torch tensor (H, W, 3) float32` is supplied by the caller: the HIP
+context on the GPU box, any stand-in renderer in CPU tests.
+"""
+from . import render_params
+
+
+def shard_params(width, height, spp, rank, world, max_depth=5, seed=1234, band_rows=20):
+    """JpRenderParams of rank `rank` of `world`: band b belongs to rank b % world (integrator.cc:53 bands)."""
+    return render_params(width, height, spp, max_depth, seed, band_rows=band_rows, shard_index=rank, shard_count=world)
+
+
+def bands_of(height, rank, world, band_rows=20):
+    nb = (height + band_rows - 1) // band_rows
+    return [(b * band_rows, min(height, (b + 1) * band_rows)) for b in range(nb) if b % world == rank]
+
+
+def render_sharded(render_fn, width, height, spp, max_depth=5, seed=1234, band_rows=20, dist=None):
+    """Every rank renders its bands; the films are summed onto rank 0.  Returns the full film on rank 0, None elsewhere."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return render_fn(shard_params(width, height, spp, 0, 1, max_depth, seed, band_rows))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    film = render_fn(shard_params(width, height, spp, rank, world, max_depth, seed, band_rows))
+    dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+    return film if rank == 0 else None

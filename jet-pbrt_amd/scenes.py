@@ -272,7 +272,7 @@ def build_cornell(be, width, height, lambert_only=False, extras=None, env=(0.0, 
     return be
 
 
-def build_bunny(be, width, height, n_lon=187, n_lat=188, instances=4):
+def build_bunny(be, width, height, n_lon=187, n_lat=188, instances=4, obj_path=None):
     """create_bunny_scene main.cc:64-111 with the procedural stand-in mesh (4 instances as in the reference)."""
     lookfrom = np.array([-300, 300, -300], np.float32); lookat = np.array([0, 0, 0], np.float32)
     be.camera(lookfrom, _normalize(lookat - lookfrom), (0, 1, 0), 60.0, width, height)
@@ -283,7 +283,7 @@ def build_bunny(be, width, height, n_lon=187, n_lat=188, instances=4):
     mat_light = be.mat_matte((0.65, 0.65, 0.65))
     be.rect(AXIS_XZ, -100, 100, -100, 100, 350, True, mat_light, light_radiance())
     be.rect(AXIS_XZ, -200, 200, -200, 200, 0, False, green, None)
-    obj = bunny_asset(n_lon, n_lat)
+    obj = obj_path or bunny_asset(n_lon, n_lat)
     kd = np.array([0.35, 0.12, 0.48], np.float32)
     mats = [lambda: red,
             lambda: be.mat_plastic(kd, (np.float32(1) - kd).astype(np.float32), 0.1, False),

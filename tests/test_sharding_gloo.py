@@ -1,0 +1,56 @@
+"""CPU suite, part 4: the N > 1 path.  Two processes over gloo: each renders the bands of its rank, one
+reduce(sum) assembles the film on rank 0, which must equal the single-rank film BIT FOR BIT (disjoint bands,
+counter sampler).  The stand-in renderer on the CPU is the oracle; on the GPU box the same plumbing
+(jet_pbrt_amd.distributed) drives the HIP context."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, W, Hh, spp, out_path):
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    import harness as H
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hb = H.SCENES["cornell"](H.scenes.HostBackend("g"), W, Hh)
+    sp = hb.flatten()
+
+    def render_fn(params):
+        film, _ = H.oracle_render(sp, params, 2)
+        own = H.jp.distributed.bands_of(Hh, params.shard_index, max(1, params.shard_count))
+        mask = np.zeros(Hh, bool)
+        for y0, y1 in own:
+            mask[y0:y1] = True
+        assert (film[~mask] == 0).all() and (film[mask].sum() > 0)       # zero outside the rank's bands
+        return torch.from_numpy(film)
+
+    film = H.jp.distributed.render_sharded(render_fn, W, Hh, spp, dist=dist)
+    if rank == 0:
+        np.save(out_path, film.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,Hh,spp", [(40, 70, 2)])
+def test_two_rank_band_shard_equals_single_rank(H, tmp_path, W, Hh, spp):
+    out = str(tmp_path / "film.npy")
+    port = 29500 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(2, port, W, Hh, spp, out), nprocs=2, join=True)
+    sharded = np.load(out)
+    hb = H.SCENES["cornell"](H.scenes.HostBackend("g"), W, Hh)
+    full, _ = H.oracle_render(hb.flatten(), H.jp.render_params(W, Hh, spp), 2)
+    assert np.array_equal(sharded.view(np.uint32), full.view(np.uint32))
+
+
+def test_band_assignment(H):
+    b0 = H.jp.distributed.bands_of(70, 0, 3); b1 = H.jp.distributed.bands_of(70, 1, 3); b2 = H.jp.distributed.bands_of(70, 2, 3)
+    assert b0 == [(0, 20), (60, 70)] and b1 == [(20, 40)] and b2 == [(40, 60)]
+    rows = sorted(y for bs in (b0, b1, b2) for (a, b) in bs for y in range(a, b))
+    assert rows == list(range(70))
