@@ -71,27 +71,27 @@ struct SceneView
 // FTriangle::Intersect shape.h:291-327.  On acceptance `tmax` shrinks (ray.SetMaxT).
 __device__ __forceinline__ bool tri_hit(V3 p0, V3 p1, V3 p2, V3 n, V3 o, V3 d, float tmin, float& tmax)
 {
-	const V3 oa = p0 - o, ob = p1 - o, oc = p2 - o;
+	// the reference evaluates the three edge functions first and the plane distance second; both are pure, so the
+	// cheap test goes first here: most candidates fail the (tmin, tmax) interval and never pay for the cross products
+	const V3 oa = p0 - o;
+	const float distance = dot(n, oa) / dot(n, d);
+	if (!((distance > tmin) && (distance < tmax))) return false;
+	const V3 ob = p1 - o, oc = p2 - o;
 	const V3 v0 = cross(oc, ob), v1 = cross(ob, oa), v2 = cross(oa, oc);
 	const float v0d = dot(v0, d), v1d = dot(v1, d), v2d = dot(v2, d);
-	if (((v0d < 0) && (v1d < 0) && (v2d < 0)) || ((v0d >= 0) && (v1d >= 0) && (v2d >= 0)))
-	{
-		const float distance = dot(n, oa) / dot(n, d);
-		if ((distance > tmin) && (distance < tmax)) { tmax = distance; return true; }
-	}
+	if (((v0d < 0) && (v1d < 0) && (v2d < 0)) || ((v0d >= 0) && (v1d >= 0) && (v2d >= 0))) { tmax = distance; return true; }
 	return false;
 }
 // FRectangle::Intersect shape.h:399-435
 __device__ __forceinline__ bool rect_hit(V3 p0, V3 p1, V3 p2, V3 p3, V3 n, V3 o, V3 d, float tmin, float& tmax)
 {
-	const V3 oa = p0 - o, ob = p1 - o, oc = p2 - o, od = p3 - o;
+	const V3 oa = p0 - o;
+	const float distance = dot(n, oa) / dot(n, d);
+	if (!((distance > tmin) && (distance < tmax))) return false;
+	const V3 ob = p1 - o, oc = p2 - o, od = p3 - o;
 	const V3 v0 = cross(oc, ob), v1 = cross(ob, oa), v2 = cross(oa, od), v3 = cross(od, oc);
 	const float v0d = dot(v0, d), v1d = dot(v1, d), v2d = dot(v2, d), v3d = dot(v3, d);
-	if (((v0d < 0) && (v1d < 0) && (v2d < 0) && (v3d < 0)) || ((v0d >= 0) && (v1d >= 0) && (v2d >= 0) && (v3d >= 0)))
-	{
-		const float distance = dot(n, oa) / dot(n, d);
-		if ((distance > tmin) && (distance < tmax)) { tmax = distance; return true; }
-	}
+	if (((v0d < 0) && (v1d < 0) && (v2d < 0) && (v3d < 0)) || ((v0d >= 0) && (v1d >= 0) && (v2d >= 0) && (v3d >= 0))) { tmax = distance; return true; }
 	return false;
 }
 // FSphere::Intersect shape.h:487-526 (sqrt resolves to the double overload there; for sqrt the double rounding
@@ -121,71 +121,85 @@ __device__ __forceinline__ bool sph_hit(V3 c, float r, V3 o, V3 d, float tmin, f
 	return false;
 }
 
-// One primitive record against the ray; FPrimitive::Intersect primitive.h:39-48.
-template <typename PrimPtr>
+// One primitive record against the ray; FPrimitive::Intersect primitive.h:39-48.  kS = record stride in float4
+// units: 4 in global memory, 5 in LDS (the 80-byte stride spreads randomly indexed 64-byte records over all
+// bank groups instead of four).
+template <int kS, typename PrimPtr>
 __device__ __forceinline__ bool prim_hit(PrimPtr prims, int pi, V3 o, V3 d, float tmin, float& tmax)
 {
-	const float4 g3 = prims[4 * pi + 3];
+	const float4 g3 = prims[kS * pi + 3];
 	const int type = __float_as_int(g3.w);
-	const float4 g0 = prims[4 * pi + 0];
+	const float4 g0 = prims[kS * pi + 0];
 	if (type == JP_SHAPE_SPHERE) return sph_hit(xyz(g0), g0.w, o, d, tmin, tmax);
-	const float4 g1 = prims[4 * pi + 1], g2 = prims[4 * pi + 2];
+	const float4 g1 = prims[kS * pi + 1], g2 = prims[kS * pi + 2];
 	if (type == JP_SHAPE_TRIANGLE) return tri_hit(xyz(g0), xyz(g1), xyz(g2), xyz(g3), o, d, tmin, tmax);
 	return rect_hit(xyz(g0), xyz(g1), xyz(g2), mk(g0.w, g1.w, g2.w), xyz(g3), o, d, tmin, tmax);
 }
 
 // ---- BVH traversal (replaces FBVH_Node::Intersect bvh.h:94-103: ordered, early-out, any-hit for shadows) -------
-// `stack` is this thread's column of the LDS stack: entry k lives at stack[k * JP_BLOCK].
-// Returns the device primitive index of the accepted hit (-1: none); `tmax` holds the hit distance.
-template <bool kAnyHit, typename NodePtr, typename PrimPtr>
-__device__ __forceinline__ int traverse(NodePtr nodes, PrimPtr prims, V3 o, V3 d, float tmin, float& tmax, int* stack)
+// Driver: one ray per lane.  `stack` is this thread's column of the LDS stack (entry k at stack[k * JP_BLOCK]).
+// "while-while" form: a lane walks interior nodes until it holds a leaf, then intersects the leaf.
+// kNear (closest-hit, shallow stacks): the far child's entry distance is pushed next to its reference (a second
+// stack plane at stack[(depth + k) * JP_BLOCK]) and a popped entry that starts beyond the current hit is dropped
+// without touching its node -- in a closed room the first leaf usually holds the final hit, so most of the stack
+// dies this way.  Returns the device primitive index of the accepted hit (-1: none); `tmax` = hit distance.
+template <bool kAnyHit, bool kNear, int kS, typename NodePtr, typename PrimPtr>
+__device__ __forceinline__ int traverse(NodePtr nodes, PrimPtr prims, V3 o, V3 d, float tmin, float& tmax, int* stack, int depth)
 {
 	const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-	int hit = -1;
-	int sp = 0;
-	int cur = 0;                                                  // node 0 is the root (always interior on the device)
+	int hit = -1, sp = 0, cur = 0;                                // node 0 is the root (always interior on the device)
 	for (;;)
 	{
-		if (cur >= 0)
+		bool alive = true;
+		while (cur >= 0)
 		{
-			const float4 n0 = nodes[4 * cur + 0], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
-			// slab test, both children; fminf/fmaxf drop the NaN of 0 * inf (ray in a slab plane)
-			float lx0 = (n0.x - o.x) * ix, lx1 = (n0.w - o.x) * ix;
-			float ly0 = (n0.y - o.y) * iy, ly1 = (n1.x - o.y) * iy;
-			float lz0 = (n0.z - o.z) * iz, lz1 = (n1.y - o.z) * iz;
-			float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), tmin));
-			float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), tmax));
-			float rx0 = (n1.z - o.x) * ix, rx1 = (n2.y - o.x) * ix;
-			float ry0 = (n1.w - o.y) * iy, ry1 = (n2.z - o.y) * iy;
-			float rz0 = (n2.x - o.z) * iz, rz1 = (n2.w - o.z) * iz;
-			float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), tmin));
-			float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), tmax));
-			const bool hl = ln <= lf * 1.0000005f, hr = rn <= rf * 1.0000005f;   // conservative: never culls a true hit
+			const float4 n0 = nodes[kS * cur + 0], n1 = nodes[kS * cur + 1], n2 = nodes[kS * cur + 2], n3 = nodes[kS * cur + 3];
+			const float lx0 = (n0.x - o.x) * ix, lx1 = (n0.w - o.x) * ix;
+			const float ly0 = (n0.y - o.y) * iy, ly1 = (n1.x - o.y) * iy;
+			const float lz0 = (n0.z - o.z) * iz, lz1 = (n1.y - o.z) * iz;
+			const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), tmin));
+			const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), tmax));
+			const float rx0 = (n1.z - o.x) * ix, rx1 = (n2.y - o.x) * ix;
+			const float ry0 = (n1.w - o.y) * iy, ry1 = (n2.z - o.y) * iy;
+			const float rz0 = (n2.x - o.z) * iz, rz1 = (n2.w - o.z) * iz;
+			const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), tmin));
+			const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), tmax));
+			const bool hl = ln <= lf * 1.000002f, hr = rn <= rf * 1.000002f;   // slack >> rounding of the slab distances: never culls a true hit, also for zero-extent boxes
 			const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
 			if (hl && hr)
 			{
-				const bool leftFirst = ln <= rn;
+				const bool leftFirst = kAnyHit ? true : (ln <= rn);
 				cur = leftFirst ? cl : cr;
-				stack[sp * JP_BLOCK] = leftFirst ? cr : cl; sp++;
-				continue;
+				stack[sp * JP_BLOCK] = leftFirst ? cr : cl;
+				if (kNear) stack[(depth + sp) * JP_BLOCK] = __float_as_int(leftFirst ? rn : ln);
+				sp++;
 			}
-			if (hl) { cur = cl; continue; }
-			if (hr) { cur = cr; continue; }
-		}
-		else
-		{
-			const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
-			for (int k = 0; k < count; k++)
+			else if (hl) cur = cl;
+			else if (hr) cur = cr;
+			else
 			{
-				if (prim_hit(prims, first + k, o, d, tmin, tmax))
+				bool got = false;
+				while (sp > 0)
 				{
-					hit = first + k;
-					if (kAnyHit) return hit;
+					sp--;
+					if (kNear && __int_as_float(stack[(depth + sp) * JP_BLOCK]) * 0.999998f > tmax) continue;   // starts behind the hit
+					cur = stack[sp * JP_BLOCK]; got = true; break;
 				}
+				if (!got) { alive = false; break; }
 			}
 		}
-		if (sp == 0) break;
-		sp--; cur = stack[sp * JP_BLOCK];
+		if (!alive) break;
+		const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
+		for (int k = 0; k < count; k++)
+			if (prim_hit<kS>(prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) return hit; }
+		bool got = false;
+		while (sp > 0)
+		{
+			sp--;
+			if (kNear && __int_as_float(stack[(depth + sp) * JP_BLOCK]) * 0.999998f > tmax) continue;
+			cur = stack[sp * JP_BLOCK]; got = true; break;
+		}
+		if (!got) break;
 	}
 	return hit;
 }

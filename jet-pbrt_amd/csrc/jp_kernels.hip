@@ -5,13 +5,15 @@
 // One batch = all pixels of this GPU's bands x S samples = P path slots (slot = s_local * NPIX + pixel).
 //   k_raygen   camera samples -> ray queue                         (sampler.h:148-155, camera.h:52-58)
 //   per bounce:
-//   k_extend   closest hit per queued ray: BVH traversal with an LDS stack, scene in LDS when it fits
-//   k_shade    emission, material closure, NEE light samples -> shadow queue, BSDF sample, Russian roulette,
-//              surviving paths compacted into the next ray queue (wave ballots + block prefix + one atomic)
+//   k_extend   closest hit per queued ray: BVH traversal with an LDS stack (+ entry distances for early pops),
+//              scene in LDS when it fits
+//   k_shade    emission, material closure, NEE light samples -> shadow rays, BSDF sample, Russian roulette,
+//              surviving paths compacted (wave ballots + block prefix) into the next ray queue
 //   k_shadow   any-hit traversal per shadow entry, visible contributions added to the path's radiance in light order
 //   k_resolve  per pixel: sequential fp32 sum over the batch's samples in index order (integrator.cc:102-105)
-// All queues are SoA float4 arrays in HBM; launches are asynchronous on one stream with no host round trip
-// inside a batch (queue lengths live in device memory, kernels are grid-stride over them).
+// Queues are SoA float4 arrays in HBM cut into one REGION per workgroup: block b reads region b of the input queue
+// and appends to region b of the output queues with a running offset, so compaction needs no global atomic and the
+// layout is deterministic.  Launches are asynchronous on one stream, no host round trip inside a batch.
 #include "jp_shading.h"
 
 #include <cstdio>
@@ -28,7 +30,7 @@ using namespace jp;
 // ---------------------------------------------------------------------------------------------------------------------
 struct DevCounters
 {
-	unsigned int n_queue[2];
+	unsigned int n_queue[2];                   // totals (host-side drain check for null-material scenes, statistics)
 	unsigned int n_shadow;
 	unsigned int pad;
 	unsigned long long closest, closest_hit, shadow, shadow_occ;
@@ -40,8 +42,10 @@ struct Queues
 	float2 *hit;                               // (t, device prim index or -1) per queued ray
 	float4 *lacc;                              // per slot: radiance of the path so far
 	float4 *sh_o;                              // per shadow entry: (origin, slot | count << 24)
-	float4 *sh_d, *sh_c;                       // plane k at [k * cap + q]: (dir, tmax), (contribution, -)
-	unsigned int cap;                          // path slots P
+	float4 *sh_d, *sh_c;                       // plane k at [k * cap + q]: (dir, tmax), (contribution, visible flag)
+	unsigned int *blk_q[2], *blk_sh;           // per-block fill of the regions
+	unsigned int cap;                          // G * R entries per queue array
+	unsigned int R;                            // region capacity (multiple of JP_BLOCK); block b owns [b*R, (b+1)*R)
 };
 
 struct RenderConst
@@ -68,121 +72,156 @@ __device__ __forceinline__ void pixel_of(const RenderConst& rc, int pix, int& x,
 	y = (rc.shard_index + j * rc.shard_count) * rc.band_rows + (r - j * rc.band_rows);
 }
 
-// block-wide allocation of one output slot per flagged thread: wave ballot + popcount prefix, per-wave totals
-// through LDS, ONE atomic per block on the queue counter.  Every thread of the block must call it.
-__device__ __forceinline__ unsigned int block_alloc(bool flag, unsigned int* counter, unsigned int* s_tmp /* [JP_BLOCK/64 + 1] */)
+// block-wide exclusive prefix of a per-thread flag: wave ballot + popcount, per-wave totals through LDS.
+// Returns this thread's offset inside the block and the block total; every thread of the block must call it.
+__device__ __forceinline__ unsigned int block_prefix(bool flag, unsigned int* s_tmp /* [JP_BLOCK/64] */, unsigned int& total)
 {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const unsigned long long m = __ballot(flag);
-	const unsigned int prefix = __popcll(m & ((1ull << lane) - 1ull));
+	const unsigned int prefix = (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
 	__syncthreads();                                         // s_tmp reuse guard
 	if (lane == 0) s_tmp[wave] = (unsigned int)__popcll(m);
 	__syncthreads();
-	if (threadIdx.x == 0)
-	{
-		unsigned int tot = 0;
-		for (int w = 0; w < JP_BLOCK / 64; w++) { unsigned int t = s_tmp[w]; s_tmp[w] = tot; tot += t; }
-		s_tmp[JP_BLOCK / 64] = tot ? atomicAdd(counter, tot) : 0u;
-	}
-	__syncthreads();
-	return s_tmp[JP_BLOCK / 64] + s_tmp[wave] + prefix;
+	unsigned int base = 0, tot = 0;
+	#pragma unroll
+	for (int w = 0; w < JP_BLOCK / 64; w++) { const unsigned int t = s_tmp[w]; if (w < wave) base += t; tot += t; }
+	total = tot;
+	return base + prefix;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_raygen: FSampler::GetCameraSample (sampler.h:148-155) + FCamera::GenerateRay (camera.h:52-58)
+// k_raygen: FSampler::GetCameraSample (sampler.h:148-155) + FCamera::GenerateRay (camera.h:52-58).
+// Block b takes the 256-slot chunks b, b+G, b+2G, ... (an even sample of the image, so every region ages alike) and
+// writes them contiguously into region b of queue 0.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(JP_BLOCK) k_raygen(SceneView sc, Queues q, RenderConst rc, DevCounters* cnt)
 {
 	const unsigned int total = (unsigned int)rc.npix * rc.sbatch;
-	if (blockIdx.x == 0 && threadIdx.x == 0) { cnt->n_queue[0] = total; cnt->n_queue[1] = 0; cnt->n_shadow = 0; }
-	for (unsigned int slot = blockIdx.x * JP_BLOCK + threadIdx.x; slot < total; slot += gridDim.x * JP_BLOCK)
+	const unsigned int nchunks = (total + JP_BLOCK - 1) / JP_BLOCK;
+	const unsigned int G = gridDim.x, b = blockIdx.x;
+	if (b == 0 && threadIdx.x == 0) { cnt->n_queue[0] = total; cnt->n_queue[1] = 0; cnt->n_shadow = 0; }
+	unsigned int filled = 0;
+	for (unsigned int c = b, j0 = 0; c < nchunks; c += G, j0 += JP_BLOCK)
 	{
-		const int pix = slot % rc.npix, s = rc.s0 + slot / rc.npix;
-		int x, y; pixel_of(rc, pix, x, y);
-		const uint32_t key = jp_rng_key(rc.seed, (uint32_t)x, (uint32_t)y, (uint32_t)s);
-		const float fx = (float)x + jp_rng_float(key, 0), fy = (float)y + jp_rng_float(key, 1);
-		const V3 front = mk(sc.cam.front[0], sc.cam.front[1], sc.cam.front[2]);
-		const V3 right = mk(sc.cam.right[0], sc.cam.right[1], sc.cam.right[2]);
-		const V3 up = mk(sc.cam.up[0], sc.cam.up[1], sc.cam.up[2]);
-		V3 dir = front + right * (fx / sc.cam.res_x - 0.5f) + up * (0.5f - fy / sc.cam.res_y);
-		dir = normalize(dir);
-		q.ray_o[0][slot] = make_float4(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2], __int_as_float((int)slot));
-		q.ray_d[0][slot] = make_float4(dir.x, dir.y, dir.z, __int_as_float(MK_FLAGS(0, 0, 2)));
-		q.beta[0][slot] = make_float4(1.f, 1.f, 1.f, __int_as_float((int)key));
-		q.lacc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+		const unsigned int slot = c * JP_BLOCK + threadIdx.x;
+		if (slot < total)
+		{
+			const unsigned int i = b * q.R + j0 + threadIdx.x;
+			const int pix = slot % rc.npix, s = rc.s0 + slot / rc.npix;
+			int x, y; pixel_of(rc, pix, x, y);
+			const uint32_t key = jp_rng_key(rc.seed, (uint32_t)x, (uint32_t)y, (uint32_t)s);
+			const float fx = (float)x + jp_rng_float(key, 0), fy = (float)y + jp_rng_float(key, 1);
+			const V3 front = mk(sc.cam.front[0], sc.cam.front[1], sc.cam.front[2]);
+			const V3 right = mk(sc.cam.right[0], sc.cam.right[1], sc.cam.right[2]);
+			const V3 up = mk(sc.cam.up[0], sc.cam.up[1], sc.cam.up[2]);
+			V3 dir = front + right * (fx / sc.cam.res_x - 0.5f) + up * (0.5f - fy / sc.cam.res_y);
+			dir = normalize(dir);
+			q.ray_o[0][i] = make_float4(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2], __int_as_float((int)slot));
+			q.ray_d[0][i] = make_float4(dir.x, dir.y, dir.z, __int_as_float(MK_FLAGS(0, 0, 2)));
+			q.beta[0][i] = make_float4(1.f, 1.f, 1.f, __int_as_float((int)key));
+			q.lacc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+		const unsigned int left = total - c * JP_BLOCK;
+		filled += left < JP_BLOCK ? left : JP_BLOCK;
 	}
+	if (threadIdx.x == 0) q.blk_q[0][b] = filled;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// scene staging into LDS for the traversal kernels
+// LDS layout of the traversal kernels: [stack: planes * depth * 256 ints][nodes][prims]; planes = 2 when the scene
+// is LDS-resident (references + entry distances), 1 otherwise
 // ---------------------------------------------------------------------------------------------------------------------
-extern __shared__ float4 s_dyn[];      // [stack: depth * JP_BLOCK ints][nodes][prims]   (16-byte aligned base)
+extern __shared__ float4 s_dyn[];      // 16-byte aligned base
 
 template <bool kLds>
 struct SceneAccess;
 template <> struct SceneAccess<false>
 {
+	static constexpr int kS = 4;
+	static constexpr bool kNear = false;
 	const float4 *nodes, *prims; int* stack;
 	__device__ __forceinline__ SceneAccess(const SceneView& sc, int depth) : nodes(sc.nodes), prims(sc.prims), stack((int*)s_dyn + threadIdx.x) { (void)depth; }
 };
 template <> struct SceneAccess<true>
 {
+	static constexpr int kS = 5;                 // 80-byte record stride in LDS (bank spreading), 64 bytes used
+	static constexpr bool kNear = true;
 	float4 *nodes, *prims; int* stack;
 	__device__ __forceinline__ SceneAccess(const SceneView& sc, int depth)
 	{
 		stack = (int*)s_dyn + threadIdx.x;
-		nodes = s_dyn + (depth * JP_BLOCK) / 4;
-		prims = nodes + 4 * sc.n_nodes;
-		for (int i = threadIdx.x; i < 4 * sc.n_nodes; i += JP_BLOCK) nodes[i] = sc.nodes[i];
-		for (int i = threadIdx.x; i < 4 * sc.n_prims; i += JP_BLOCK) prims[i] = sc.prims[i];
+		nodes = s_dyn + (2 * depth * JP_BLOCK) / 4;
+		prims = nodes + 5 * sc.n_nodes;
+		for (int i = threadIdx.x; i < 4 * sc.n_nodes; i += JP_BLOCK) nodes[5 * (i >> 2) + (i & 3)] = sc.nodes[i];
+		for (int i = threadIdx.x; i < 4 * sc.n_prims; i += JP_BLOCK) prims[5 * (i >> 2) + (i & 3)] = sc.prims[i];
 		__syncthreads();
 	}
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_extend: FScene::Intersect (scene.cc:25-33) for every queued ray
+// k_extend: FScene::Intersect (scene.cc:25-33) for every ray of this block's region
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool kLds>
 __global__ void __launch_bounds__(JP_BLOCK) k_extend(SceneView sc, Queues q, int cur, int depth, DevCounters* cnt)
 {
-	__shared__ unsigned int s_hits;
 	SceneAccess<kLds> acc(sc, depth);
-	const unsigned int count = cnt->n_queue[cur];
-	if (blockIdx.x == 0 && threadIdx.x == 0) { cnt->n_queue[cur ^ 1] = 0; cnt->n_shadow = 0; cnt->closest += count; }
-	if (threadIdx.x == 0) s_hits = 0;
-	__syncthreads();
-	unsigned int myhits = 0;
-	for (unsigned int i = blockIdx.x * JP_BLOCK + threadIdx.x; i < count; i += gridDim.x * JP_BLOCK)
+	const unsigned int b = blockIdx.x, n = q.blk_q[cur][b], rbase = b * q.R;
+	if (b == 0 && threadIdx.x == 0) { cnt->closest += cnt->n_queue[cur]; cnt->n_queue[cur ^ 1] = 0; cnt->n_shadow = 0; }
+	unsigned int h = 0;
+	for (unsigned int j = threadIdx.x; j < n; j += JP_BLOCK)
 	{
+		const unsigned int i = rbase + j;
 		const float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i];
-		float tmax = JP_INF;
-		const int hit = traverse<false>(acc.nodes, acc.prims, xyz(ro), xyz(rd), 0.001f, tmax, acc.stack);   // FRay defaults geometry.h:399
+		float tmax = JP_INF;                                         // FRay defaults geometry.h:399: min_t 0.001, max_t infinity
+		const int hit = traverse<false, SceneAccess<kLds>::kNear, SceneAccess<kLds>::kS>(acc.nodes, acc.prims, xyz(ro), xyz(rd), 0.001f, tmax, acc.stack, depth);
 		q.hit[i] = make_float2(tmax, __int_as_float(hit));
-		myhits += hit >= 0 ? 1u : 0u;
+		h += hit >= 0 ? 1u : 0u;
 	}
-	const unsigned long long m = __ballot(myhits != 0);      // cheap pre-filter, then wave reduction
-	if (m)
-	{
-		for (int off = 32; off > 0; off >>= 1) myhits += __shfl_down(myhits, off);
-		if ((threadIdx.x & 63) == 0) atomicAdd(&s_hits, myhits);
-	}
-	__syncthreads();
-	if (threadIdx.x == 0 && s_hits) atomicAdd(&cnt->closest_hit, (unsigned long long)s_hits);
+	for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off);
+	if ((threadIdx.x & 63) == 0 && h) atomicAdd(&cnt->closest_hit, (unsigned long long)h);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_shade: the body of FPathIntegratorIteration::Li after the intersection (integrator.cc:328-399)
 // ---------------------------------------------------------------------------------------------------------------------
+// Table staging: lights + materials (kTab) and, for scenes whose primitives fit, primitive records + meta (kPrims)
+// are copied into LDS once per block, so the dependent lookups of a shading event (hit -> primitive -> material /
+// light) are LDS reads instead of a chain of global loads.
+template <bool kTab, bool kPrims>
 __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, RenderConst rc, int cur, DevCounters* cnt)
 {
-	__shared__ unsigned int s_tmp[JP_BLOCK / 64 + 1];
-	const unsigned int count = cnt->n_queue[cur];
+	__shared__ unsigned int s_tmp[JP_BLOCK / 64];
+	float4* s_lights = s_dyn;
+	float4* s_mats = s_lights + 2 * sc.n_lights;
+	float4* s_prims = s_mats + 4 * sc.n_mats;
+	int4* s_meta = (int4*)(s_prims + 4 * sc.n_prims);
+	int* s_mtype = kPrims ? (int*)(s_meta + sc.n_prims) : (int*)s_prims;
+	const unsigned int b = blockIdx.x, n = q.blk_q[cur][b];
 	const int nxt = cur ^ 1;
-	const unsigned int nloops = (count + gridDim.x * JP_BLOCK - 1) / (gridDim.x * JP_BLOCK);
-	for (unsigned int it = 0; it < nloops; it++)
+	if (n == 0) { if (threadIdx.x == 0) { q.blk_q[nxt][b] = 0; q.blk_sh[b] = 0; } return; }
+	if (kTab)
 	{
-		const unsigned int i = (it * gridDim.x + blockIdx.x) * JP_BLOCK + threadIdx.x;
-		const bool valid = i < count;
+		for (int i = threadIdx.x; i < 2 * sc.n_lights; i += JP_BLOCK) s_lights[i] = sc.lights[i];
+		for (int i = threadIdx.x; i < 4 * sc.n_mats; i += JP_BLOCK) s_mats[i] = sc.mats[i];
+		for (int i = threadIdx.x; i < sc.n_mats; i += JP_BLOCK) s_mtype[i] = sc.mat_type[i];
+	}
+	if (kPrims)
+	{
+		for (int i = threadIdx.x; i < 4 * sc.n_prims; i += JP_BLOCK) s_prims[i] = sc.prims[i];
+		for (int i = threadIdx.x; i < sc.n_prims; i += JP_BLOCK) s_meta[i] = sc.meta[i];
+	}
+	if (kTab || kPrims) __syncthreads();
+	const float4* lights = kTab ? (const float4*)s_lights : sc.lights;
+	const float4* mats = kTab ? (const float4*)s_mats : sc.mats;
+	const int* mat_type = kTab ? (const int*)s_mtype : sc.mat_type;
+	const float4* prims = kPrims ? (const float4*)s_prims : sc.prims;
+	const int4* meta_t = kPrims ? (const int4*)s_meta : sc.meta;
+	const unsigned int rbase = b * q.R;
+	unsigned int run_q = 0, run_sh = 0;                           // block-uniform fill of this block's output regions
+	for (unsigned int j0 = 0; j0 < n; j0 += JP_BLOCK)
+	{
+		const unsigned int i = rbase + j0 + threadIdx.x;
+		const bool valid = j0 + threadIdx.x < n;
 		bool shaded = false, wantNee = false, alive = false;
 		V3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(0, 0, 0), p = mk(0, 0, 0), N = mk(0, 0, 1);
 		int slot = 0, bounce = 0; bool spec = false; unsigned int dim = 0; uint32_t key = 0;
@@ -201,18 +240,18 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 			V3 Le = splat(0);
 			if (found)
 			{
-				const float4 g3 = sc.prims[4 * pi + 3];
-				const int4 meta = sc.meta[pi];
+				const float4 g3 = prims[4 * pi + 3];
+				const int4 meta = meta_t[pi];
 				const int type = __float_as_int(g3.w);
 				p = o + h.x * d;                                                      // ray(distance) geometry.h:412-416
 				if (type == JP_SHAPE_TRIANGLE) N = xyz(g3);
 				else if (type == JP_SHAPE_RECTANGLE) N = dot(xyz(g3), d) <= 0 ? xyz(g3) : -xyz(g3);   // shape.h:427
-				else { const float4 g0 = sc.prims[4 * pi]; N = normalize(p - xyz(g0)); }              // shape.h:521
+				else { const float4 g0 = prims[4 * pi]; N = normalize(p - xyz(g0)); }              // shape.h:521
 				mat = meta.y;
 				if (meta.z >= 0 && (bounce == 0 || spec))                             // primitive.h:60-63, light.h:234-238
 				{
 					const V3 wo = -d;
-					if (dot(N, wo) > 0.f) Le = xyz(sc.lights[2 * meta.z]);
+					if (dot(N, wo) > 0.f) Le = xyz(lights[2 * meta.z]);
 				}
 			}
 			else if (bounce == 0 || spec)                                             // integrator.cc:334-336, light.h:300-303
@@ -220,7 +259,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				// L += beta * Le for each infinite light in order; folded on the host only when there is at most one
 				for (int li = 0; li < sc.n_lights; li++)
 				{
-					const float4 l0 = sc.lights[2 * li];
+					const float4 l0 = lights[2 * li];
 					if (__float_as_int(l0.w) == JP_LIGHT_ENVIRONMENT && !isblack(xyz(l0)))
 					{
 						float4 L = q.lacc[slot];
@@ -241,8 +280,9 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				else
 				{
 					float up = 0.f;
-					if (sc.mat_type[mat] == JP_MAT_PLASTIC) up = jp_rng_float(key, dim++);   // material.cc:14
-					make_closure(sc, mat, up, c);
+					const int mtype = mat_type[mat];
+					if (mtype == JP_MAT_PLASTIC) up = jp_rng_float(key, dim++);   // material.cc:14
+					make_closure(mats, mtype, mat, up, c);
 					fr = frame_from_z(N);
 					shaded = true;
 					wantNee = !is_delta(c);
@@ -250,7 +290,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 			}
 		}
 		// ---- next-event estimation: one shadow entry per non-delta shaded path (integrator.cc:357-372) ----
-		const unsigned int qs = block_alloc(wantNee, &cnt->n_shadow, s_tmp);
+		unsigned int tot_sh; const unsigned int qs = rbase + run_sh + block_prefix(wantNee, s_tmp, tot_sh); run_sh += tot_sh;
 		V3 nd = d, nbeta = beta; int nbounce = bounce; bool nspec = spec;
 		if (shaded)
 		{
@@ -261,13 +301,17 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				int k = 0;
 				for (int li = 0; li < sc.n_lights; li++)
 				{
-					const float ux = jp_rng_float(key, dim), uy = jp_rng_float(key, dim + 1); dim += 2;
-					LightSample ls = sample_li(sc, sc.prims, li, p, N, ux, uy);
+					const unsigned int d0 = dim; dim += 2;                              // the two draws are consumed even when the sample is rejected
+					const float4 lrad = lights[2 * li];
+					if (isblack(xyz(lrad))) continue;                                   // Li would be black (integrator.cc:362): skip the evaluation, keep the draws
+					const float ux = jp_rng_float(key, d0), uy = jp_rng_float(key, d0 + 1);
+					LightSample ls = sample_li(sc, prims, lights, li, p, N, ux, uy);
 					if (isblack(ls.Li) || ls.pdf == 0.f) continue;
 					const V3 f = eval_local(c, wo, to_local(fr, ls.wi));               // FBSDF::Evalf bsdf.h:284-287
 					if (isblack(f)) continue;
 					// FScene::Occluded scene.h:36-47: dir and distance recomputed from the sampled position
-					const V3 sdir = normalize(ls.pos - p);
+					// (for an area light Normalize(target - position) is the very expression that produced ls.wi)
+					const V3 sdir = __float_as_int(lrad.w) == JP_LIGHT_AREA ? ls.wi : normalize(ls.pos - p);
 					const float dist = len(p - ls.pos);
 					const V3 contrib = cmul(cmul(beta, f), ls.Li) * absdot(ls.wi, N) / ls.pdf;   // integrator.cc:369
 					if (k < rc.n_planes)
@@ -305,7 +349,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 			}
 		}
 		// ---- compact survivors into the next ray queue ----
-		const unsigned int j = block_alloc(alive, &cnt->n_queue[nxt], s_tmp);
+		unsigned int tot_q; const unsigned int j = rbase + run_q + block_prefix(alive, s_tmp, tot_q); run_q += tot_q;
 		if (alive)
 		{
 			q.ray_o[nxt][j] = make_float4(p.x, p.y, p.z, __int_as_float(slot));       // SpawnRay shape.h:61-64
@@ -313,45 +357,49 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 			q.beta[nxt][j] = make_float4(nbeta.x, nbeta.y, nbeta.z, __int_as_float((int)key));
 		}
 	}
+	if (threadIdx.x == 0)
+	{
+		q.blk_q[nxt][b] = run_q; q.blk_sh[b] = run_sh;
+		if (run_q) atomicAdd(&cnt->n_queue[nxt], run_q);
+		if (run_sh) atomicAdd(&cnt->n_shadow, run_sh);
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_shadow: FScene::Occluded (scene.h:36-47) for the entry's rays in light order; L += contribution when visible
+// (integrator.cc:367-370).  One lane owns a path's entry, so the path's radiance is summed in exactly the
+// reference's order and the film is run-to-run deterministic (no float atomics).
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool kLds>
-__global__ void __launch_bounds__(JP_BLOCK) k_shadow(SceneView sc, Queues q, int depth, DevCounters* cnt)
+__global__ void __launch_bounds__(JP_BLOCK) k_shadow(SceneView sc, Queues q, RenderConst rc, int depth, DevCounters* cnt)
 {
-	__shared__ unsigned int s_rays, s_occ;
 	SceneAccess<kLds> acc(sc, depth);
-	const unsigned int count = cnt->n_shadow;
-	if (threadIdx.x == 0) { s_rays = 0; s_occ = 0; }
-	__syncthreads();
+	const unsigned int b = blockIdx.x, E = q.blk_sh[b], rbase = b * q.R;
 	unsigned int rays = 0, occ = 0;
-	for (unsigned int e = blockIdx.x * JP_BLOCK + threadIdx.x; e < count; e += gridDim.x * JP_BLOCK)
+	for (unsigned int j = threadIdx.x; j < E; j += JP_BLOCK)
 	{
+		const unsigned int e = rbase + j;
 		const float4 so = q.sh_o[e];
 		const int packed = __float_as_int(so.w);
 		const int slot = packed & 0xffffff, n = (packed >> 24) & 0xff;
 		if (n == 0) continue;
-		V3 add = mk(0, 0, 0); bool any = false;
-		float4 L = q.lacc[slot];
+		bool any = false;
+		const float4 L = q.lacc[slot];                               // issued up front: its latency hides behind the traversal
 		V3 a = mk(L.x, L.y, L.z);
 		for (int k = 0; k < n; k++)
 		{
 			const float4 sd = q.sh_d[(size_t)k * q.cap + e];
+			const float4 c4 = q.sh_c[(size_t)k * q.cap + e];
 			float tmax = sd.w;
-			const int hit = traverse<true>(acc.nodes, acc.prims, xyz(so), xyz(sd), 0.001f, tmax, acc.stack);
+			const int hit = traverse<true, false, SceneAccess<kLds>::kS>(acc.nodes, acc.prims, xyz(so), xyz(sd), 0.001f, tmax, acc.stack, depth);
 			rays++;
 			if (hit >= 0) occ++;
-			else { const float4 sc4 = q.sh_c[(size_t)k * q.cap + e]; a = a + xyz(sc4); any = true; }
+			else { a = a + xyz(c4); any = true; }
 		}
-		(void)add;
 		if (any) q.lacc[slot] = make_float4(a.x, a.y, a.z, 0.f);
 	}
 	for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); occ += __shfl_down(occ, off); }
-	if ((threadIdx.x & 63) == 0) { if (rays) atomicAdd(&s_rays, rays); if (occ) atomicAdd(&s_occ, occ); }
-	__syncthreads();
-	if (threadIdx.x == 0) { if (s_rays) atomicAdd(&cnt->shadow, (unsigned long long)s_rays); if (s_occ) atomicAdd(&cnt->shadow_occ, (unsigned long long)s_occ); }
+	if ((threadIdx.x & 63) == 0) { if (rays) atomicAdd(&cnt->shadow, (unsigned long long)rays); if (occ) atomicAdd(&cnt->shadow_occ, (unsigned long long)occ); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -392,7 +440,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_trace(SceneView sc, int depth, int
 	{
 		const V3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
 		float tmax = tmax_in[i];
-		const int h = traverse<false>(acc.nodes, acc.prims, ro, rd, tmin[i], tmax, acc.stack);
+		const int h = traverse<false, SceneAccess<kLds>::kNear, SceneAccess<kLds>::kS>(acc.nodes, acc.prims, ro, rd, tmin[i], tmax, acc.stack, depth);
 		hit[i] = h >= 0; t[i] = tmax; prim[i] = h >= 0 ? sc.meta[h].x : -1;
 		V3 N = mk(0, 0, 0);
 		if (h >= 0)
@@ -424,8 +472,9 @@ struct JpContext
 	SceneView sv; int stack_depth = 1; bool scene_in_lds = false; size_t lds_bytes = 0;
 	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr;
 	int n_planes = 1; bool has_null_material = false;
+	bool tables_in_lds = false; size_t shade_lds_bytes = 0;
 	// queues
-	Queues q; unsigned int cap = 0; int planes_alloc = 0;
+	Queues q; unsigned int cap = 0; int planes_alloc = 0; unsigned int blk_alloc = 0; int blocks_per_cu = 16;
 	std::vector<void*> qbufs;
 	float4* d_pix_acc = nullptr; size_t pix_acc_n = 0;
 	float* d_film = nullptr; size_t film_n = 0;
@@ -468,6 +517,7 @@ int jp_create_context(int device_id, JpContext** out)
 	c->device = device_id;
 	std::memset(&c->counters, 0, sizeof(c->counters));
 	std::memset(&c->q, 0, sizeof(c->q));
+	if (const char* e = getenv("JETPBRT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 256) c->blocks_per_cu = v; }
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount;
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess
@@ -573,7 +623,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		for (int a = 0; a < 3; a++)
 		{
 			float lo = s->bvh_bounds[6 * n + a], hi = s->bvh_bounds[6 * n + 3 + a];
-			float m = std::max(std::fabs(lo), std::fabs(hi)); float e = m * 4e-7f + 1e-6f;
+			float m = std::max(std::fabs(lo), std::fabs(hi)); float e = m * 1e-6f + 1e-6f;   // >> ulp(m): flat (zero-extent) boxes stay hittable
 			b[a] = lo - e; b[3 + a] = hi + e;
 		}
 	};
@@ -677,10 +727,16 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.env_sum = make_float3(envsum[0], envsum[1], envsum[2]); v.n_env = nenv;
 	v.world_radius = s->world_radius; v.cam = s->camera;
 	c->stack_depth = std::max(2, height + 2);
-	size_t scene_bytes = (nodes.size() + prims.size()) * sizeof(float4);
+	size_t scene_bytes = (nodes.size() + prims.size()) / 4 * 5 * sizeof(float4);   // 80-byte LDS record stride
 	size_t stack_bytes = (size_t)c->stack_depth * JP_BLOCK * sizeof(int);
-	c->scene_in_lds = scene_bytes + stack_bytes <= 48 * 1024;
+	c->scene_in_lds = scene_bytes + 2 * stack_bytes <= 40 * 1024;                   // two stack planes when LDS-resident
+	if (c->scene_in_lds) stack_bytes *= 2;
 	c->lds_bytes = stack_bytes + (c->scene_in_lds ? scene_bytes : 0);
+	{
+		size_t tab = ((size_t)2 * s->n_lights + (size_t)4 * s->n_materials) * sizeof(float4) + (size_t)s->n_materials * sizeof(int) + 16;
+		c->tables_in_lds = tab <= 16 * 1024;
+		c->shade_lds_bytes = c->tables_in_lds ? tab + (c->scene_in_lds ? prims.size() * sizeof(float4) + meta.size() * sizeof(int4) : 0) : 0;
+	}
 	c->n_planes = std::max(1, planes);
 	c->has_null_material = hasNull;
 	c->have_scene = true;
@@ -692,17 +748,19 @@ namespace
 {
 enum { CLS_EXTEND = 0, CLS_SHADE = 1, CLS_SHADOW = 2, CLS_OTHER = 3 };
 
-int ensure_queues(JpContext* c, unsigned int cap, int planes)
+int ensure_queues(JpContext* c, unsigned int cap, int planes, unsigned int nblocks)
 {
-	if (c->cap >= cap && c->planes_alloc >= planes) return JP_OK;
-	free_queues(c);
+	if (c->cap >= cap && c->planes_alloc >= planes && c->blk_alloc >= nblocks) return JP_OK;
+	cap = std::max(cap, c->cap); planes = std::max(planes, c->planes_alloc); nblocks = std::max(nblocks, c->blk_alloc);
+	free_queues(c); c->blk_alloc = 0;
 	auto alloc = [&](void** p, size_t bytes) -> bool { if (hipMalloc(p, bytes) != hipSuccess) return false; c->qbufs.push_back(*p); return true; };
 	Queues& q = c->q; bool ok = true;
-	for (int b = 0; b < 2 && ok; b++) ok = alloc((void**)&q.ray_o[b], (size_t)cap * 16) && alloc((void**)&q.ray_d[b], (size_t)cap * 16) && alloc((void**)&q.beta[b], (size_t)cap * 16);
+	for (int b = 0; b < 2 && ok; b++) ok = alloc((void**)&q.ray_o[b], (size_t)cap * 16) && alloc((void**)&q.ray_d[b], (size_t)cap * 16) && alloc((void**)&q.beta[b], (size_t)cap * 16)
+	                                       && alloc((void**)&q.blk_q[b], (size_t)nblocks * 4);
 	ok = ok && alloc((void**)&q.hit, (size_t)cap * 8) && alloc((void**)&q.lacc, (size_t)cap * 16) && alloc((void**)&q.sh_o, (size_t)cap * 16)
-	     && alloc((void**)&q.sh_d, (size_t)cap * 16 * planes) && alloc((void**)&q.sh_c, (size_t)cap * 16 * planes);
+	     && alloc((void**)&q.sh_d, (size_t)cap * 16 * planes) && alloc((void**)&q.sh_c, (size_t)cap * 16 * planes) && alloc((void**)&q.blk_sh, (size_t)nblocks * 4);
 	if (!ok) { free_queues(c); return fail(JP_ERR_DEVICE, "jp_render: out of device memory for the path queues"); }
-	q.cap = cap; c->cap = cap; c->planes_alloc = planes;
+	c->cap = cap; c->planes_alloc = planes; c->blk_alloc = nblocks;
 	return JP_OK;
 }
 
@@ -749,16 +807,22 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 		size_t freeB = 0, totalB = 0; hipMemGetInfo(&freeB, &totalB);
 		size_t per = 136 + 32 * (size_t)c->n_planes;
 		size_t budget = std::min<size_t>((size_t)24 << 30, (freeB + (c->cap ? (size_t)c->cap * (136 + 32 * (size_t)c->planes_alloc) : 0)) / 2);
+		if (const char* e = getenv("JETPBRT_MAX_SLOTS")) { long long v = atoll(e); if (v > 0) budget = std::min<size_t>(budget, (size_t)v * per); }
 		unsigned int pcap = (unsigned int)std::min<size_t>(PMAX, std::max<size_t>((size_t)npix, budget / per));
 		int sbatch = (int)std::max<long long>(1, std::min<long long>(rp->spp, pcap / npix));
 		if ((long long)sbatch * npix > (long long)PMAX) return fail(JP_ERR_UNSUPPORTED, "jp_render: shard too large for one batch");
-		unsigned int cap = (unsigned int)((long long)sbatch * npix);
-		int st = ensure_queues(c, cap, c->n_planes); if (st != JP_OK) return st;
+		const unsigned int P = (unsigned int)((long long)sbatch * npix);
+		const unsigned int nchunks = (P + JP_BLOCK - 1) / JP_BLOCK;
+		const unsigned int G = std::max(1u, std::min(nchunks, (unsigned int)(c->n_cus * c->blocks_per_cu)));   // one region per workgroup
+		const unsigned int R = ((nchunks + G - 1) / G) * JP_BLOCK;
+		const unsigned int cap = G * R;
+		int st = ensure_queues(c, cap, c->n_planes, G); if (st != JP_OK) return st;
+		c->q.cap = cap; c->q.R = R;
 		if (c->pix_acc_n < (size_t)npix) { if (c->d_pix_acc) hipFree(c->d_pix_acc); c->d_pix_acc = nullptr; HIP_TRY(hipMalloc((void**)&c->d_pix_acc, (size_t)npix * 16)); c->pix_acc_n = (size_t)npix; }
 
 		RenderConst rc; rc.width = rp->width; rc.height = rp->height; rc.spp = rp->spp; rc.max_depth = rp->max_depth; rc.seed = rp->seed;
-		rc.band_rows = band; rc.shard_index = sidx; rc.shard_count = scount; rc.npix = (int)npix; rc.local_rows = local_rows; rc.n_planes = c->planes_alloc < c->n_planes ? c->planes_alloc : c->n_planes;
-		const int grid = c->n_cus * 8;
+		rc.band_rows = band; rc.shard_index = sidx; rc.shard_count = scount; rc.npix = (int)npix; rc.local_rows = local_rows; rc.n_planes = c->n_planes;
+		const int grid = (int)G;
 		const size_t lds = c->lds_bytes;
 		for (int s0 = 0; s0 < rp->spp; s0 += sbatch)
 		{
@@ -780,15 +844,20 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 					if (c->scene_in_lds) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
 					else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
 				}
-				{ Stamper t(c, CLS_SHADE); hipLaunchKernelGGL(k_shade, dim3(grid), dim3(JP_BLOCK), 0, c->stream, c->sv, c->q, rc, cur, c->d_cnt); }
+				{
+					Stamper t(c, CLS_SHADE);
+					if (c->tables_in_lds && c->scene_in_lds) hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(JP_BLOCK), c->shade_lds_bytes, c->stream, c->sv, c->q, rc, cur, c->d_cnt);
+					else if (c->tables_in_lds) hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(JP_BLOCK), c->shade_lds_bytes, c->stream, c->sv, c->q, rc, cur, c->d_cnt);
+					else hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(JP_BLOCK), 0, c->stream, c->sv, c->q, rc, cur, c->d_cnt);
+				}
 				{
 					Stamper t(c, CLS_SHADOW);
-					if (c->scene_in_lds) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, c->stack_depth, c->d_cnt);
-					else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, c->stack_depth, c->d_cnt);
+					if (c->scene_in_lds) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
+					else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 				}
 				cur ^= 1;
 			}
-			{ Stamper t(c, CLS_OTHER); hipLaunchKernelGGL(k_resolve, dim3((unsigned int)std::min<long long>(grid, (npix + JP_BLOCK - 1) / JP_BLOCK)), dim3(JP_BLOCK), 0, c->stream, c->q, rc, c->d_pix_acc, film_dev, s0 == 0 ? 1 : 0, s0 + rc.sbatch >= rp->spp ? 1 : 0); }
+			{ Stamper t(c, CLS_OTHER); hipLaunchKernelGGL(k_resolve, dim3((unsigned int)std::min<long long>(c->n_cus * 8, (npix + JP_BLOCK - 1) / JP_BLOCK)), dim3(JP_BLOCK), 0, c->stream, c->q, rc, c->d_pix_acc, film_dev, s0 == 0 ? 1 : 0, s0 + rc.sbatch >= rp->spp ? 1 : 0); }
 			samples += (unsigned long long)rc.sbatch * (unsigned long long)npix;
 		}
 		HIP_TRY(hipGetLastError());

@@ -4,15 +4,46 @@
 // see jp_device.h for the numerics rules.
 //
 // Transcendentals: the reference calls glibc sinf/cosf (results within ~0.56 ulp, not bit-reproducible across
-// hosts).  The device evaluates sin/cos in fp64 and rounds once to fp32 -- the correctly rounded value in all
-// but ~1e-8 of cases, which coincides with glibc's result wherever glibc is correctly rounded.
+// hosts).  The device evaluates sin/cos in fp64 (sincos_d below) and rounds once to fp32 -- the correctly rounded
+// value in all but ~1e-9 of cases, which coincides with glibc's result wherever glibc is correctly rounded.
 #pragma once
 #include "jp_device.h"
 
 namespace jp
 {
-__device__ __forceinline__ float sin_f(float x) { return (float)sin((double)x); }
-__device__ __forceinline__ float cos_f(float x) { return (float)cos((double)x); }
+// sin and cos of an fp32 argument, evaluated in fp64 and rounded once to fp32.  |x| stays below ~7 on every call
+// site (angles in [-pi/4, 2 pi]), so one Cody-Waite step by pi/2 (two-part constant, exact product via fma) plus
+// the Taylor polynomials to x^15 / x^16 on [-pi/4, pi/4] give an absolute error < 2e-16 -- the rounded fp32
+// value is the correctly rounded sine/cosine except when the true value lies within ~1e-9 ulp of a rounding
+// boundary.  ~25 fp64 operations for the pair, no table, no Payne-Hanek path.
+__device__ __forceinline__ void sincos_d(float xf, double* s, double* c)
+{
+	const double x = (double)xf;
+	const double kd = rint(x * 0.63661977236758134308);
+	const int k = (int)kd;
+	double r = fma(-kd, 1.57079632679489655800e+00, x);
+	r = fma(-kd, 6.12323399573676603587e-17, r);
+	const double r2 = r * r;
+	double sp = fma(r2, -7.6471637318198164759e-13, 1.6059043836821614599e-10);      // -1/15!, 1/13!
+	sp = fma(sp, r2, -2.5052108385441718775e-08);                                     // -1/11!
+	sp = fma(sp, r2, 2.7557319223985890653e-06);                                      // 1/9!
+	sp = fma(sp, r2, -1.9841269841269841270e-04);                                     // -1/7!
+	sp = fma(sp, r2, 8.3333333333333333333e-03);                                      // 1/5!
+	sp = fma(sp, r2, -1.6666666666666666667e-01);                                     // -1/3!
+	sp = fma(sp * r2, r, r);
+	double cp = fma(r2, 4.7794773323873852974e-14, -1.1470745597729724714e-11);      // 1/16!, -1/14!
+	cp = fma(cp, r2, 2.0876756987868098979e-09);                                      // 1/12!
+	cp = fma(cp, r2, -2.7557319223985890653e-07);                                     // -1/10!
+	cp = fma(cp, r2, 2.4801587301587301587e-05);                                      // 1/8!
+	cp = fma(cp, r2, -1.3888888888888888889e-03);                                     // -1/6!
+	cp = fma(cp, r2, 4.1666666666666666667e-02);                                      // 1/4!
+	cp = fma(cp, r2, -0.5);
+	cp = fma(cp, r2, 1.0);
+	const double ss = (k & 1) ? cp : sp, cc = (k & 1) ? sp : cp;
+	*s = (k & 2) ? -ss : ss;
+	*c = ((k + 1) & 2) ? -cc : cc;
+}
+__device__ __forceinline__ void sincos_f(float xf, float* s, float* c) { double sd, cd; sincos_d(xf, &sd, &cd); *s = (float)sd; *c = (float)cd; }
 
 #define JP_2PI      (2.0f * JP_PI)
 #define JP_PI_OVER2 (JP_PI / 2.0f)
@@ -58,7 +89,8 @@ __device__ __forceinline__ V3 cosine_hemisphere(float ux, float uy)             
 		float radius, theta;
 		if (fabsf(ux) > fabsf(uy)) { radius = ux; theta = JP_PI_OVER4 * (uy / ux); }
 		else { radius = uy; theta = JP_PI_OVER2 - JP_PI_OVER4 * (ux / uy); }
-		px = cos_f(theta) * radius; py = sin_f(theta) * radius;
+		float st, ct; sincos_f(theta, &st, &ct);
+		px = ct * radius; py = st * radius;
 	}
 	float z = sqrtf(smax(0.f, 1 - px * px - py * py));
 	return mk(px, py, z);
@@ -68,7 +100,8 @@ __device__ __forceinline__ V3 uniform_sphere(float ux, float uy)                
 	float z = 1 - 2 * ux;
 	float radius = sqrtf(smax(0.f, 1.f - z * z));
 	float phi = 2 * JP_PI * uy;
-	return mk(radius * cos_f(phi), radius * sin_f(phi), z);
+	float sp, cp; sincos_f(phi, &sp, &cp);
+	return mk(radius * cp, radius * sp, z);
 }
 
 // ---- local-frame helpers (bsdf.h:17-60) ------------------------------------------------------------------------------
@@ -148,8 +181,9 @@ __device__ __forceinline__ void tr_sample11(float cosTheta, float U1, float U2, 
 	{
 		float r = sqrtf(U1 / (1 - U1));                     // double sqrt of an fp32 value, rounded back: same value
 		float phi = 6.28318530718f * U2;
-		*slope_x = (float)((double)r * cos((double)phi));
-		*slope_y = (float)((double)r * sin((double)phi));
+		double sd, cd; sincos_d(phi, &sd, &cd);
+		*slope_x = (float)((double)r * cd);
+		*slope_y = (float)((double)r * sd);
 		return;
 	}
 	float sinTheta = sqrtf(smax(0.f, 1.f - cosTheta * cosTheta));
@@ -277,10 +311,10 @@ __device__ __forceinline__ BsdfSample sample_local(const Closure& c, V3 wo, floa
 
 // FMaterial::Scattering (material.h:34-37, 52-55, 72-75; material.cc:12-43).  `uplastic` is the draw
 // FPlasticMaterial consumes (material.cc:14); the caller draws it only for JP_MAT_PLASTIC.
-__device__ __forceinline__ void make_closure(const SceneView& sc, int mat, float uplastic, Closure& c)
+template <typename MatPtr>
+__device__ __forceinline__ void make_closure(MatPtr mats, int type, int mat, float uplastic, Closure& c)
 {
-	const int type = sc.mat_type[mat];
-	const float4 p0 = sc.mats[4 * mat + 0], p1 = sc.mats[4 * mat + 1];
+	const float4 p0 = mats[4 * mat + 0], p1 = mats[4 * mat + 1];
 	c.c0 = splat(0); c.c1 = splat(0); c.eta_t = 1; c.ax = c.ay = 0; c.fresnel = FR_CONDUCTOR; c.feta = splat(0); c.fk = splat(0);
 	if (type == JP_MAT_MATTE) { c.kind = CL_LAMBERT; c.c0 = xyz(p0); }
 	else if (type == JP_MAT_MIRROR) { c.kind = CL_MIRROR; c.c0 = xyz(p0); }
@@ -300,17 +334,16 @@ struct LightSample { V3 pos, wi; float pdf; V3 Li; };
 // FLight::Sample_Li for light `li` from surface point p with normal n (isect.normal, used by the sphere's
 // inside branch only).  light.h:199-216 (area), :265-291 (environment); shape sampling shape.h:124-145, 353-363,
 // 459-467, 549-644.
-template <typename PrimPtr>
-__device__ __forceinline__ LightSample sample_li(const SceneView& sc, PrimPtr prims, int li, V3 p, V3 n_isect, float ux, float uy)
+template <typename PrimPtr, typename LightPtr>
+__device__ __forceinline__ LightSample sample_li(const SceneView& sc, PrimPtr prims, LightPtr lights, int li, V3 p, V3 n_isect, float ux, float uy)
 {
 	LightSample s; s.pos = mk(0, 0, 0); s.wi = mk(0, 0, 0); s.pdf = 0; s.Li = splat(0);
-	const float4 l0 = sc.lights[2 * li], l1 = sc.lights[2 * li + 1];
+	const float4 l0 = lights[2 * li], l1 = lights[2 * li + 1];
 	const V3 radiance = xyz(l0);
 	if (__float_as_int(l0.w) == JP_LIGHT_ENVIRONMENT)
 	{
 		float theta = uy * JP_PI, phi = ux * 2 * JP_PI;
-		float cosT = cos_f(theta), sinT = sin_f(theta);
-		float sinP = sin_f(phi), cosP = cos_f(phi);
+		float cosT, sinT, sinP, cosP; sincos_f(theta, &sinT, &cosT); sincos_f(phi, &sinP, &cosP);
 		s.wi = mk(sinT * cosP, sinT * sinP, cosT);
 		s.pos = p + s.wi * 2 * sc.world_radius;
 		if (sinT != 0) s.pdf = 1 / (2 * JP_PI * JP_PI * sinT);
@@ -371,7 +404,8 @@ __device__ __forceinline__ LightSample sample_li(const SceneView& sc, PrimPtr pr
 			float sin_alpha = sqrtf(smax(0.f, 1.f - cos_alpha * cos_alpha));
 			float phi = uy * 2 * JP_PI;
 			Frame fr = frame_from_z((c - p) * inv_dist);
-			V3 wn = sin_alpha * cos_f(phi) * (-fr.s) + sin_alpha * sin_f(phi) * (-fr.t) + cos_alpha * (-fr.n);
+			float sphi, cphi; sincos_f(phi, &sphi, &cphi);
+			V3 wn = sin_alpha * cphi * (-fr.s) + sin_alpha * sphi * (-fr.t) + cos_alpha * (-fr.n);
 			lp = c + r * wn; ln = wn;
 			pdf = 1 / (2 * JP_PI * (1 - cos_max));
 		}

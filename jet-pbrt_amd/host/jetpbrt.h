@@ -78,7 +78,8 @@ public:
 	virtual ~FShape() = default;
 	virtual int Kind() const = 0;                                // JP_SHAPE_*
 	const FBounds3& WorldBounds() const { return worldBox; }
-	FBounds3 worldBox;
+	FBounds3 worldBox;          // the reference's bounds (thin boxes padded by 0.01, geometry.h:299-304): world bound / env radius
+	FBounds3 tightBox;          // exact extent: what our own BVH is built over (padding happens at upload, relative)
 };
 
 class FTriangle : public FShape                                  // shape.h:277-369

@@ -47,7 +47,7 @@ FTriangle::FTriangle(const FPoint3& a, const FPoint3& b, const FPoint3& c, bool 
 {
 	normal = Normalize(Cross(p1 - p0, p2 - p0));                          // shape.h:284-286
 	if (flip_normal) normal = -normal;
-	FBounds3 bbox(p0, p1); bbox = bbox.Join(p2); bbox.CheckThinness();    // shape.h:342-349
+	FBounds3 bbox(p0, p1); bbox = bbox.Join(p2); tightBox = bbox; bbox.CheckThinness();    // shape.h:342-349
 	worldBox = bbox;
 }
 
@@ -55,7 +55,7 @@ FRectangle::FRectangle(const FPoint3& a, const FPoint3& b, const FPoint3& c, con
 {
 	normal = Normalize(Cross(p1 - p0, p2 - p0));                          // shape.h:388-390
 	if (flip_normal) normal = -normal;
-	FBounds3 bbox = FBounds3(p0, p1).Join(p2).Join(p3); bbox.CheckThinness();
+	FBounds3 bbox = FBounds3(p0, p1).Join(p2).Join(p3); tightBox = bbox; bbox.CheckThinness();
 	worldBox = bbox;
 }
 FRectangle FRectangle::FromXY(Float x0, Float x1, Float y0, Float y1, Float z, bool f)
@@ -69,6 +69,7 @@ FSphere::FSphere(const FVector3& c, Float r) : center(c), radius(r)
 {
 	FVector3 half(r, r, r);
 	worldBox = FBounds3(center + half, center - half);                    // shape.h:540-544
+	tightBox = worldBox;
 }
 
 // ---- OBJ ingest: own reader, the reference's vertex transform (shape.cc:23-68) ------------------------------
@@ -202,7 +203,9 @@ void FScene::Preprocess()                                                // scen
 	worldBound = bound;
 	for (auto& l : lights) l->Preprocess(*this);
 	std::vector<FBounds3> pb; pb.reserve(primitives.size());
-	for (auto& p : primitives) pb.push_back(p->shape->WorldBounds());
+	// own BVH over the exact extents: a ray leaving a flat surface (min_t 0.001) or ending 0.001 short of a light
+	// then misses that surface's box instead of visiting its leaf through the reference's 0.01 thinness pad
+	for (auto& p : primitives) pb.push_back(p->shape->tightBox);
 	BuildBVH(pb, bvh);
 	preprocessed = true;
 }
