@@ -133,47 +133,66 @@ __global__ void __launch_bounds__(JP_BLOCK) k_raygen(SceneView sc, Queues q, Ren
 // ---------------------------------------------------------------------------------------------------------------------
 extern __shared__ float4 s_dyn[];      // 16-byte aligned base
 
-template <bool kLds>
+// kMode 0: BVH and primitives in global memory (L2 / Infinity Cache resident), one stack plane in LDS
+// kMode 1: BVH + primitives staged into LDS, two stack planes (references + entry distances)
+// kMode 2: tiny scene: flat leaf list (uniform loads from global), primitives in LDS, no stack
+template <int kMode>
 struct SceneAccess;
-template <> struct SceneAccess<false>
+template <> struct SceneAccess<0>
 {
-	static constexpr int kS = 4;
-	static constexpr bool kNear = false;
-	const float4 *nodes, *prims; int* stack;
-	__device__ __forceinline__ SceneAccess(const SceneView& sc, int depth) : nodes(sc.nodes), prims(sc.prims), stack((int*)s_dyn + threadIdx.x) { (void)depth; }
+	const float4 *nodes, *prims; int* stack; int depth;
+	__device__ __forceinline__ SceneAccess(const SceneView& sc, int depth_) : nodes(sc.nodes), prims(sc.prims), stack((int*)s_dyn + threadIdx.x), depth(depth_) {}
+	template <bool kAnyHit> __device__ __forceinline__ int trace(const SceneView&, V3 o, V3 d, float tmin, float& tmax) const
+	{ return traverse<kAnyHit, false, 4>(nodes, prims, o, d, tmin, tmax, stack, depth); }
 };
-template <> struct SceneAccess<true>
+template <> struct SceneAccess<1>
 {
-	static constexpr int kS = 5;                 // 80-byte record stride in LDS (bank spreading), 64 bytes used
-	static constexpr bool kNear = true;
-	float4 *nodes, *prims; int* stack;
-	__device__ __forceinline__ SceneAccess(const SceneView& sc, int depth)
+	float4 *nodes, *prims; int* stack; int depth;
+	__device__ __forceinline__ SceneAccess(const SceneView& sc, int depth_) : depth(depth_)
 	{
 		stack = (int*)s_dyn + threadIdx.x;
 		nodes = s_dyn + (2 * depth * JP_BLOCK) / 4;
-		prims = nodes + 5 * sc.n_nodes;
+		prims = nodes + 5 * sc.n_nodes;              // 80-byte record stride in LDS (bank spreading), 64 bytes used
 		for (int i = threadIdx.x; i < 4 * sc.n_nodes; i += JP_BLOCK) nodes[5 * (i >> 2) + (i & 3)] = sc.nodes[i];
 		for (int i = threadIdx.x; i < 4 * sc.n_prims; i += JP_BLOCK) prims[5 * (i >> 2) + (i & 3)] = sc.prims[i];
 		__syncthreads();
 	}
+	template <bool kAnyHit> __device__ __forceinline__ int trace(const SceneView&, V3 o, V3 d, float tmin, float& tmax) const
+	{ return traverse<kAnyHit, !kAnyHit, 5>(nodes, prims, o, d, tmin, tmax, stack, depth); }
+};
+template <> struct SceneAccess<2>
+{
+	float4* prims;
+	__device__ __forceinline__ SceneAccess(const SceneView& sc, int)
+	{
+		prims = s_dyn;
+		for (int i = threadIdx.x; i < 4 * sc.n_prims; i += JP_BLOCK) prims[5 * (i >> 2) + (i & 3)] = sc.prims[i];
+		__syncthreads();
+	}
+	template <bool kAnyHit> __device__ __forceinline__ int trace(const SceneView& sc, V3 o, V3 d, float tmin, float& tmax) const
+	{ return traverse_flat<kAnyHit, 5>(sc.flat, sc.n_flat, prims, o, d, tmin, tmax); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_extend: FScene::Intersect (scene.cc:25-33) for every ray of this block's region
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool kLds>
+template <int kMode>
 __global__ void __launch_bounds__(JP_BLOCK) k_extend(SceneView sc, Queues q, int cur, int depth, DevCounters* cnt)
 {
-	SceneAccess<kLds> acc(sc, depth);
+	SceneAccess<kMode> acc(sc, depth);
 	const unsigned int b = blockIdx.x, n = q.blk_q[cur][b], rbase = b * q.R;
 	if (b == 0 && threadIdx.x == 0) { cnt->closest += cnt->n_queue[cur]; cnt->n_queue[cur ^ 1] = 0; cnt->n_shadow = 0; }
 	unsigned int h = 0;
+	// software prefetch: the next iteration's ray is requested before this iteration's traversal
+	float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 1, 0);
+	if (threadIdx.x < n) { ro = q.ray_o[cur][rbase + threadIdx.x]; rd = q.ray_d[cur][rbase + threadIdx.x]; }
 	for (unsigned int j = threadIdx.x; j < n; j += JP_BLOCK)
 	{
 		const unsigned int i = rbase + j;
-		const float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i];
+		const float4 co = ro, cd = rd;
+		if (j + JP_BLOCK < n) { ro = q.ray_o[cur][i + JP_BLOCK]; rd = q.ray_d[cur][i + JP_BLOCK]; }
 		float tmax = JP_INF;                                         // FRay defaults geometry.h:399: min_t 0.001, max_t infinity
-		const int hit = traverse<false, SceneAccess<kLds>::kNear, SceneAccess<kLds>::kS>(acc.nodes, acc.prims, xyz(ro), xyz(rd), 0.001f, tmax, acc.stack, depth);
+		const int hit = acc.template trace<false>(sc, xyz(co), xyz(cd), 0.001f, tmax);
 		q.hit[i] = make_float2(tmax, __int_as_float(hit));
 		h += hit >= 0 ? 1u : 0u;
 	}
@@ -370,16 +389,20 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 // (integrator.cc:367-370).  One lane owns a path's entry, so the path's radiance is summed in exactly the
 // reference's order and the film is run-to-run deterministic (no float atomics).
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool kLds>
+template <int kMode>
 __global__ void __launch_bounds__(JP_BLOCK) k_shadow(SceneView sc, Queues q, RenderConst rc, int depth, DevCounters* cnt)
 {
-	SceneAccess<kLds> acc(sc, depth);
+	SceneAccess<kMode> acc(sc, depth);
 	const unsigned int b = blockIdx.x, E = q.blk_sh[b], rbase = b * q.R;
 	unsigned int rays = 0, occ = 0;
+	// software prefetch: the next entry's header and first ray are requested before this entry is traced
+	float4 so_n = make_float4(0, 0, 0, 0), sd_n = make_float4(0, 0, 1, 0);
+	if (threadIdx.x < E) { so_n = q.sh_o[rbase + threadIdx.x]; sd_n = q.sh_d[rbase + threadIdx.x]; }
 	for (unsigned int j = threadIdx.x; j < E; j += JP_BLOCK)
 	{
 		const unsigned int e = rbase + j;
-		const float4 so = q.sh_o[e];
+		const float4 so = so_n; float4 sd = sd_n;
+		if (j + JP_BLOCK < E) { so_n = q.sh_o[e + JP_BLOCK]; sd_n = q.sh_d[e + JP_BLOCK]; }
 		const int packed = __float_as_int(so.w);
 		const int slot = packed & 0xffffff, n = (packed >> 24) & 0xff;
 		if (n == 0) continue;
@@ -388,10 +411,11 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shadow(SceneView sc, Queues q, Ren
 		V3 a = mk(L.x, L.y, L.z);
 		for (int k = 0; k < n; k++)
 		{
-			const float4 sd = q.sh_d[(size_t)k * q.cap + e];
-			const float4 c4 = q.sh_c[(size_t)k * q.cap + e];
+			const float4 c4 = q.sh_c[(size_t)k * q.cap + e];          // needed only after the traversal
 			float tmax = sd.w;
-			const int hit = traverse<true, false, SceneAccess<kLds>::kS>(acc.nodes, acc.prims, xyz(so), xyz(sd), 0.001f, tmax, acc.stack, depth);
+			const V3 dir = xyz(sd);
+			if (k + 1 < n) sd = q.sh_d[(size_t)(k + 1) * q.cap + e];
+			const int hit = acc.template trace<true>(sc, xyz(so), dir, 0.001f, tmax);
 			rays++;
 			if (hit >= 0) occ++;
 			else { a = a + xyz(c4); any = true; }
@@ -431,16 +455,16 @@ __global__ void __launch_bounds__(JP_BLOCK) k_resolve(Queues q, RenderConst rc, 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_trace: test hook, arbitrary rays through the same traversal
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool kLds>
+template <int kMode>
 __global__ void __launch_bounds__(JP_BLOCK) k_trace(SceneView sc, int depth, int n, const float* o, const float* d, const float* tmin, const float* tmax_in,
                                                     int* hit, float* t, int* prim, float* nrm)
 {
-	SceneAccess<kLds> acc(sc, depth);
+	SceneAccess<kMode> acc(sc, depth);
 	for (int i = blockIdx.x * JP_BLOCK + threadIdx.x; i < n; i += gridDim.x * JP_BLOCK)
 	{
 		const V3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
 		float tmax = tmax_in[i];
-		const int h = traverse<false, SceneAccess<kLds>::kNear, SceneAccess<kLds>::kS>(acc.nodes, acc.prims, ro, rd, tmin[i], tmax, acc.stack, depth);
+		const int h = acc.template trace<false>(sc, ro, rd, tmin[i], tmax);
 		hit[i] = h >= 0; t[i] = tmax; prim[i] = h >= 0 ? sc.meta[h].x : -1;
 		V3 N = mk(0, 0, 0);
 		if (h >= 0)
@@ -470,6 +494,7 @@ struct JpContext
 	// scene
 	bool have_scene = false;
 	SceneView sv; int stack_depth = 1; bool scene_in_lds = false; size_t lds_bytes = 0;
+	void* d_flat = nullptr; int trav_mode = 0;
 	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr;
 	int n_planes = 1; bool has_null_material = false;
 	bool tables_in_lds = false; size_t shade_lds_bytes = 0;
@@ -490,7 +515,7 @@ struct JpContext
 
 static void free_scene(JpContext* c)
 {
-	void** ps[] = { &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights };
+	void** ps[] = { &c->d_flat, &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights };
 	for (void** p : ps) { if (*p) hipFree(*p); *p = nullptr; }
 	c->have_scene = false;
 }
@@ -680,6 +705,24 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	}
 	if (meta.size() >= (1u << 27)) return fail(JP_ERR_UNSUPPORTED, "jp_upload_scene: too many primitives for the leaf reference encoding");
 
+	// tiny scenes: the flat leaf list of traverse_flat (leaf boxes padded like the node boxes)
+	std::vector<float4> flat;
+	{
+		int nleaves = 0; for (int n = 0; n < s->n_bvh_nodes; n++) if (seen[n] && s->bvh_left[n] < 0) nleaves++;
+		if (nleaves <= 32)
+		{
+			for (int n = 0; n < s->n_bvh_nodes; n++)
+			{
+				if (!seen[n] || s->bvh_left[n] >= 0) continue;
+				float bb[6]; pad_box(n, bb);
+				int first = -s->bvh_left[n] - 1, cnt = s->bvh_right[n];
+				int dfirst = devPrimOf[s->bvh_prim_index[first]];                 // leaf primitives are contiguous on the device
+				float f0, f1; std::memcpy(&f0, &dfirst, 4); std::memcpy(&f1, &cnt, 4);
+				flat.push_back(make_float4(bb[0], bb[1], bb[2], f0)); flat.push_back(make_float4(bb[3], bb[4], bb[5], f1));
+			}
+		}
+	}
+
 	// materials: the 16-float rows as 4 x float4
 	std::vector<float4> mats(4 * std::max(1, s->n_materials)); std::vector<int> mtype(std::max(1, s->n_materials), 0);
 	for (int i = 0; i < s->n_materials; i++) { std::memcpy(&mats[4 * i], s->mat_params + (size_t)i * JP_MAT_PARAM_STRIDE, 16 * sizeof(float)); mtype[i] = s->mat_type[i]; }
@@ -718,6 +761,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	HIP_TRY(up(&c->d_mats, mats.data(), mats.size() * sizeof(float4)));
 	HIP_TRY(up(&c->d_mat_type, mtype.data(), mtype.size() * sizeof(int)));
 	HIP_TRY(up(&c->d_lights, lights.data(), lights.size() * sizeof(float4)));
+	if (!flat.empty()) HIP_TRY(up(&c->d_flat, flat.data(), flat.size() * sizeof(float4)));
 
 	SceneView& v = c->sv;
 	v.nodes = (const float4*)c->d_nodes; v.n_nodes = (int)nodes.size() / 4;
@@ -726,12 +770,15 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.lights = (const float4*)c->d_lights; v.n_lights = s->n_lights;
 	v.env_sum = make_float3(envsum[0], envsum[1], envsum[2]); v.n_env = nenv;
 	v.world_radius = s->world_radius; v.cam = s->camera;
+	v.flat = (const float4*)c->d_flat; v.n_flat = (int)flat.size() / 2;
 	c->stack_depth = std::max(2, height + 2);
 	size_t scene_bytes = (nodes.size() + prims.size()) / 4 * 5 * sizeof(float4);   // 80-byte LDS record stride
+	size_t prim_bytes = prims.size() / 4 * 5 * sizeof(float4);
 	size_t stack_bytes = (size_t)c->stack_depth * JP_BLOCK * sizeof(int);
 	c->scene_in_lds = scene_bytes + 2 * stack_bytes <= 40 * 1024;                   // two stack planes when LDS-resident
-	if (c->scene_in_lds) stack_bytes *= 2;
-	c->lds_bytes = stack_bytes + (c->scene_in_lds ? scene_bytes : 0);
+	c->trav_mode = (!flat.empty() && prim_bytes <= 40 * 1024) ? 2 : (c->scene_in_lds ? 1 : 0);
+	if (const char* e = getenv("JETPBRT_TRAVERSAL")) { int m = atoi(e); if (m == 0 || (m == 1 && c->scene_in_lds)) c->trav_mode = m; }   // experiments: force a lower mode
+	c->lds_bytes = c->trav_mode == 2 ? prim_bytes : (c->trav_mode == 1 ? 2 * stack_bytes + scene_bytes : stack_bytes);
 	{
 		size_t tab = ((size_t)2 * s->n_lights + (size_t)4 * s->n_materials) * sizeof(float4) + (size_t)s->n_materials * sizeof(int) + 16;
 		c->tables_in_lds = tab <= 16 * 1024;
@@ -841,8 +888,9 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 				}
 				{
 					Stamper t(c, CLS_EXTEND);
-					if (c->scene_in_lds) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
-					else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
+					if (c->trav_mode == 2) hipLaunchKernelGGL(k_extend<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
+					else if (c->trav_mode == 1) hipLaunchKernelGGL(k_extend<1>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
+					else hipLaunchKernelGGL(k_extend<0>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
 				}
 				{
 					Stamper t(c, CLS_SHADE);
@@ -852,8 +900,9 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 				}
 				{
 					Stamper t(c, CLS_SHADOW);
-					if (c->scene_in_lds) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
-					else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
+					if (c->trav_mode == 2) hipLaunchKernelGGL(k_shadow<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
+					else if (c->trav_mode == 1) hipLaunchKernelGGL(k_shadow<1>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
+					else hipLaunchKernelGGL(k_shadow<0>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 				}
 				cur ^= 1;
 			}
@@ -934,8 +983,9 @@ int jp_trace(JpContext* c, int32_t n, const float* origin, const float* dir, con
 		hipMemcpyAsync(d_o, origin, (size_t)n * 12, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(d_d, dir, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
 		hipMemcpyAsync(d_t0, tmin, (size_t)n * 4, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(d_t1, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
 		int grid = std::min(c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK);
-		if (c->scene_in_lds) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
-		else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
+		if (c->trav_mode == 2) hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
+		else if (c->trav_mode == 1) hipLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
+		else hipLaunchKernelGGL(k_trace<0>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		hipMemcpyAsync(hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream); hipMemcpyAsync(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
 		hipMemcpyAsync(prim, d_prim, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream); hipMemcpyAsync(normal, d_n, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream);
 		hipError_t e = hipStreamSynchronize(c->stream);

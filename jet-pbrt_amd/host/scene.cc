@@ -206,7 +206,9 @@ void FScene::Preprocess()                                                // scen
 	// own BVH over the exact extents: a ray leaving a flat surface (min_t 0.001) or ending 0.001 short of a light
 	// then misses that surface's box instead of visiting its leaf through the reference's 0.01 thinness pad
 	for (auto& p : primitives) pb.push_back(p->shape->tightBox);
-	BuildBVH(pb, bvh);
+	int maxLeaf = 4;
+	if (const char* e = getenv("JETPBRT_BVH_MAXLEAF")) { int v = atoi(e); if (v >= 1 && v <= 16) maxLeaf = v; }
+	BuildBVH(pb, bvh, maxLeaf);
 	preprocessed = true;
 }
 
