@@ -65,7 +65,7 @@ struct SceneView
 	int n_env;
 	float world_radius;
 	JpCamera cam;
-	const float4* flat; int n_flat;         // tiny scenes: one (box min, first | box max, count) pair per BVH leaf, <= 32 leaves
+	const float4* flat; const int* flat_leaf; int n_flat;   // tiny scenes: leaf boxes + (first | count-1 << 24), <= 32 leaves, padded to x4
 };
 
 // ---- shape intersection: exact restatements ---------------------------------------------------------------------
@@ -210,29 +210,36 @@ __device__ __forceinline__ int traverse(NodePtr nodes, PrimPtr prims, V3 o, V3 d
 // broadcast) operands -- no stack, no pointer chasing, all 64 lanes busy -- and records the boxes the ray enters
 // in a per-lane bit mask.  Phase 2 walks the lane's own set bits and runs the exact primitive tests.  For the
 // Cornell box this replaces ~6-8 dependent binary-node steps per ray by 17 independent slab tests.
-// flat[2i] = (box min xyz, first device primitive), flat[2i+1] = (box max xyz, primitive count), as int bits in .w
+// flat[2i] = (box min xyz, -), flat[2i+1] = (box max xyz, -); the list is padded to a multiple of 4 with boxes that can
+// never be hit, so the slab loop runs in fully unrolled groups of four (scalar loads issued together).
+// leaf[i] = first device primitive | (count - 1) << 24, kept in LDS (indexed per lane in phase 2).
 typedef const __attribute__((address_space(4))) float* ConstFPtr;       // constant address space: uniform indices become scalar (s_load) loads
 template <bool kAnyHit, int kS, typename PrimPtr>
-__device__ __forceinline__ int traverse_flat(const float4* flat_g, int n_flat, PrimPtr prims, V3 o, V3 d, float tmin, float& tmax)
+__device__ __forceinline__ int traverse_flat(const float4* flat_g, int n_flat4, const int* leaf, PrimPtr prims, V3 o, V3 d, float tmin, float& tmax)
 {
 	ConstFPtr flat = (ConstFPtr)flat_g;
 	const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
 	unsigned int mask = 0;
-	for (int i = 0; i < n_flat; i++)
+	for (int i0 = 0; i0 < n_flat4; i0 += 4)
 	{
-		const float x0 = (flat[8 * i + 0] - o.x) * ix, x1 = (flat[8 * i + 4] - o.x) * ix;
-		const float y0 = (flat[8 * i + 1] - o.y) * iy, y1 = (flat[8 * i + 5] - o.y) * iy;
-		const float z0 = (flat[8 * i + 2] - o.z) * iz, z1 = (flat[8 * i + 6] - o.z) * iz;
-		const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-		const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
-		if (tn <= tf * 1.000002f) mask |= 1u << i;
+		#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const int i = i0 + u;
+			const float x0 = (flat[8 * i + 0] - o.x) * ix, x1 = (flat[8 * i + 4] - o.x) * ix;
+			const float y0 = (flat[8 * i + 1] - o.y) * iy, y1 = (flat[8 * i + 5] - o.y) * iy;
+			const float z0 = (flat[8 * i + 2] - o.z) * iz, z1 = (flat[8 * i + 6] - o.z) * iz;
+			const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+			const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+			if (tn <= tf * 1.000002f) mask |= 1u << i;
+		}
 	}
 	int hit = -1;
 	while (mask)
 	{
 		const int i = __ffs((int)mask) - 1;
 		mask &= mask - 1;
-		const int first = __float_as_int(flat_g[2 * i].w), count = __float_as_int(flat_g[2 * i + 1].w);
+		const int lf = leaf[i], first = lf & 0xffffff, count = ((unsigned int)lf >> 24) + 1;
 		for (int k = 0; k < count; k++)
 			if (prim_hit<kS>(prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) return hit; }
 	}

@@ -162,15 +162,17 @@ template <> struct SceneAccess<1>
 };
 template <> struct SceneAccess<2>
 {
-	float4* prims;
+	float4* prims; int* leaf;
 	__device__ __forceinline__ SceneAccess(const SceneView& sc, int)
 	{
-		prims = s_dyn;
+		leaf = (int*)s_dyn;                                   // 32 ints
+		prims = s_dyn + 8;
+		for (int i = threadIdx.x; i < sc.n_flat; i += JP_BLOCK) leaf[i] = sc.flat_leaf[i];
 		for (int i = threadIdx.x; i < 4 * sc.n_prims; i += JP_BLOCK) prims[5 * (i >> 2) + (i & 3)] = sc.prims[i];
 		__syncthreads();
 	}
 	template <bool kAnyHit> __device__ __forceinline__ int trace(const SceneView& sc, V3 o, V3 d, float tmin, float& tmax) const
-	{ return traverse_flat<kAnyHit, 5>(sc.flat, sc.n_flat, prims, o, d, tmin, tmax); }
+	{ return traverse_flat<kAnyHit, 5>(sc.flat, sc.n_flat, leaf, prims, o, d, tmin, tmax); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -206,7 +208,9 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend(SceneView sc, Queues q, int
 // Table staging: lights + materials (kTab) and, for scenes whose primitives fit, primitive records + meta (kPrims)
 // are copied into LDS once per block, so the dependent lookups of a shading event (hit -> primitive -> material /
 // light) are LDS reads instead of a chain of global loads.
-template <bool kTab, bool kPrims>
+// kStage (<= 4 emitting lights): the NEE rays of a path are staged in LDS and a shadow entry is allocated only when at
+// least one ray survived the rejections of integrator.cc:362-367, so k_shadow never meets an empty entry.
+template <bool kTab, bool kPrims, bool kStage>
 __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, RenderConst rc, int cur, DevCounters* cnt)
 {
 	__shared__ unsigned int s_tmp[JP_BLOCK / 64];
@@ -215,6 +219,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 	float4* s_prims = s_mats + 4 * sc.n_mats;
 	int4* s_meta = (int4*)(s_prims + 4 * sc.n_prims);
 	int* s_mtype = kPrims ? (int*)(s_meta + sc.n_prims) : (int*)s_prims;
+	float4* s_stage = (float4*)(((uintptr_t)(s_mtype + sc.n_mats) + 15) & ~(uintptr_t)15) + threadIdx.x;   // [(2k, 2k+1) * 256 + tid]
 	const unsigned int b = blockIdx.x, n = q.blk_q[cur][b];
 	const int nxt = cur ^ 1;
 	if (n == 0) { if (threadIdx.x == 0) { q.blk_q[nxt][b] = 0; q.blk_sh[b] = 0; } return; }
@@ -237,18 +242,21 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 	const int4* meta_t = kPrims ? (const int4*)s_meta : sc.meta;
 	const unsigned int rbase = b * q.R;
 	unsigned int run_q = 0, run_sh = 0;                           // block-uniform fill of this block's output regions
+	// software prefetch of the next chunk's path records
+	float4 ro_n = make_float4(0, 0, 0, 0), rd_n = ro_n, rb_n = ro_n; float2 h_n = make_float2(0, 0);
+	if (threadIdx.x < n) { const unsigned int i0 = rbase + threadIdx.x; ro_n = q.ray_o[cur][i0]; rd_n = q.ray_d[cur][i0]; rb_n = q.beta[cur][i0]; h_n = q.hit[i0]; }
 	for (unsigned int j0 = 0; j0 < n; j0 += JP_BLOCK)
 	{
 		const unsigned int i = rbase + j0 + threadIdx.x;
 		const bool valid = j0 + threadIdx.x < n;
+		const float4 ro = ro_n, rd = rd_n, rb = rb_n; const float2 h = h_n;
+		if (j0 + JP_BLOCK + threadIdx.x < n) { ro_n = q.ray_o[cur][i + JP_BLOCK]; rd_n = q.ray_d[cur][i + JP_BLOCK]; rb_n = q.beta[cur][i + JP_BLOCK]; h_n = q.hit[i + JP_BLOCK]; }
 		bool shaded = false, wantNee = false, alive = false;
 		V3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(0, 0, 0), p = mk(0, 0, 0), N = mk(0, 0, 1);
 		int slot = 0, bounce = 0; bool spec = false; unsigned int dim = 0; uint32_t key = 0;
 		Closure c; c.kind = CL_LAMBERT; Frame fr; fr.s = fr.t = fr.n = mk(0, 0, 1);
 		if (valid)
 		{
-			const float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i], rb = q.beta[cur][i];
-			const float2 h = q.hit[i];
 			o = xyz(ro); d = xyz(rd); beta = xyz(rb);
 			slot = __float_as_int(ro.w); key = (uint32_t)__float_as_int(rb.w);
 			const int flags = __float_as_int(rd.w);
@@ -308,16 +316,18 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				}
 			}
 		}
-		// ---- next-event estimation: one shadow entry per non-delta shaded path (integrator.cc:357-372) ----
-		unsigned int tot_sh; const unsigned int qs = rbase + run_sh + block_prefix(wantNee, s_tmp, tot_sh); run_sh += tot_sh;
+		// ---- next-event estimation (integrator.cc:357-372) ----
+		unsigned int qs = 0;
+		if (!kStage) { unsigned int tot_sh; qs = rbase + run_sh + block_prefix(wantNee, s_tmp, tot_sh); run_sh += tot_sh; }
 		V3 nd = d, nbeta = beta; int nbounce = bounce; bool nspec = spec;
+		V3 wo = mk(0, 0, 1);
+		int k = 0;
 		if (shaded)
 		{
 			const V3 wo_w = -d;
-			const V3 wo = to_local(fr, wo_w);
+			wo = to_local(fr, wo_w);
 			if (wantNee)
 			{
-				int k = 0;
 				for (int li = 0; li < sc.n_lights; li++)
 				{
 					const unsigned int d0 = dim; dim += 2;                              // the two draws are consumed even when the sample is rejected
@@ -335,13 +345,37 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 					const V3 contrib = cmul(cmul(beta, f), ls.Li) * absdot(ls.wi, N) / ls.pdf;   // integrator.cc:369
 					if (k < rc.n_planes)
 					{
-						q.sh_d[(size_t)k * q.cap + qs] = make_float4(sdir.x, sdir.y, sdir.z, dist - 0.001f);
-						q.sh_c[(size_t)k * q.cap + qs] = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
+						if (kStage)
+						{
+							s_stage[(2 * k) * JP_BLOCK] = make_float4(sdir.x, sdir.y, sdir.z, dist - 0.001f);
+							s_stage[(2 * k + 1) * JP_BLOCK] = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
+						}
+						else
+						{
+							q.sh_d[(size_t)k * q.cap + qs] = make_float4(sdir.x, sdir.y, sdir.z, dist - 0.001f);
+							q.sh_c[(size_t)k * q.cap + qs] = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
+						}
 						k++;
 					}
 				}
-				q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
+				if (!kStage) q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
 			}
+		}
+		if (kStage)
+		{
+			unsigned int tot_sh; qs = rbase + run_sh + block_prefix(k > 0, s_tmp, tot_sh); run_sh += tot_sh;
+			if (k > 0)
+			{
+				q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
+				for (int kk = 0; kk < k; kk++)
+				{
+					q.sh_d[(size_t)kk * q.cap + qs] = s_stage[(2 * kk) * JP_BLOCK];
+					q.sh_c[(size_t)kk * q.cap + qs] = s_stage[(2 * kk + 1) * JP_BLOCK];
+				}
+			}
+		}
+		if (shaded)
+		{
 			// ---- BSDF sample (integrator.cc:375-379) ----
 			const float ux = jp_rng_float(key, dim), uy = jp_rng_float(key, dim + 1); dim += 2;
 			BsdfSample bs = sample_local(c, wo, ux, uy);
@@ -494,10 +528,10 @@ struct JpContext
 	// scene
 	bool have_scene = false;
 	SceneView sv; int stack_depth = 1; bool scene_in_lds = false; size_t lds_bytes = 0;
-	void* d_flat = nullptr; int trav_mode = 0;
+	void *d_flat = nullptr, *d_flat_leaf = nullptr; int trav_mode = 0;
 	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr;
 	int n_planes = 1; bool has_null_material = false;
-	bool tables_in_lds = false; size_t shade_lds_bytes = 0;
+	bool tables_in_lds = false, stage_nee = false; size_t shade_lds_bytes = 0;
 	// queues
 	Queues q; unsigned int cap = 0; int planes_alloc = 0; unsigned int blk_alloc = 0; int blocks_per_cu = 16;
 	std::vector<void*> qbufs;
@@ -515,7 +549,7 @@ struct JpContext
 
 static void free_scene(JpContext* c)
 {
-	void** ps[] = { &c->d_flat, &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights };
+	void** ps[] = { &c->d_flat, &c->d_flat_leaf, &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights };
 	for (void** p : ps) { if (*p) hipFree(*p); *p = nullptr; }
 	c->have_scene = false;
 }
@@ -705,8 +739,8 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	}
 	if (meta.size() >= (1u << 27)) return fail(JP_ERR_UNSUPPORTED, "jp_upload_scene: too many primitives for the leaf reference encoding");
 
-	// tiny scenes: the flat leaf list of traverse_flat (leaf boxes padded like the node boxes)
-	std::vector<float4> flat;
+	// tiny scenes: the flat leaf list of traverse_flat (leaf boxes padded like the node boxes, list padded to x4)
+	std::vector<float4> flat; std::vector<int> flat_leaf;
 	{
 		int nleaves = 0; for (int n = 0; n < s->n_bvh_nodes; n++) if (seen[n] && s->bvh_left[n] < 0) nleaves++;
 		if (nleaves <= 32)
@@ -717,9 +751,10 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 				float bb[6]; pad_box(n, bb);
 				int first = -s->bvh_left[n] - 1, cnt = s->bvh_right[n];
 				int dfirst = devPrimOf[s->bvh_prim_index[first]];                 // leaf primitives are contiguous on the device
-				float f0, f1; std::memcpy(&f0, &dfirst, 4); std::memcpy(&f1, &cnt, 4);
-				flat.push_back(make_float4(bb[0], bb[1], bb[2], f0)); flat.push_back(make_float4(bb[3], bb[4], bb[5], f1));
+				flat.push_back(make_float4(bb[0], bb[1], bb[2], 0)); flat.push_back(make_float4(bb[3], bb[4], bb[5], 0));
+				flat_leaf.push_back(dfirst | ((cnt - 1) << 24));
 			}
+			while (flat_leaf.size() % 4) { flat.push_back(make_float4(1e30f, 1e30f, 1e30f, 0)); flat.push_back(make_float4(-1e30f, -1e30f, -1e30f, 0)); flat_leaf.push_back(0); }
 		}
 	}
 
@@ -761,7 +796,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	HIP_TRY(up(&c->d_mats, mats.data(), mats.size() * sizeof(float4)));
 	HIP_TRY(up(&c->d_mat_type, mtype.data(), mtype.size() * sizeof(int)));
 	HIP_TRY(up(&c->d_lights, lights.data(), lights.size() * sizeof(float4)));
-	if (!flat.empty()) HIP_TRY(up(&c->d_flat, flat.data(), flat.size() * sizeof(float4)));
+	if (!flat.empty()) { HIP_TRY(up(&c->d_flat, flat.data(), flat.size() * sizeof(float4))); HIP_TRY(up(&c->d_flat_leaf, flat_leaf.data(), flat_leaf.size() * sizeof(int))); }
 
 	SceneView& v = c->sv;
 	v.nodes = (const float4*)c->d_nodes; v.n_nodes = (int)nodes.size() / 4;
@@ -770,7 +805,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.lights = (const float4*)c->d_lights; v.n_lights = s->n_lights;
 	v.env_sum = make_float3(envsum[0], envsum[1], envsum[2]); v.n_env = nenv;
 	v.world_radius = s->world_radius; v.cam = s->camera;
-	v.flat = (const float4*)c->d_flat; v.n_flat = (int)flat.size() / 2;
+	v.flat = (const float4*)c->d_flat; v.flat_leaf = (const int*)c->d_flat_leaf; v.n_flat = (int)flat_leaf.size();
 	c->stack_depth = std::max(2, height + 2);
 	size_t scene_bytes = (nodes.size() + prims.size()) / 4 * 5 * sizeof(float4);   // 80-byte LDS record stride
 	size_t prim_bytes = prims.size() / 4 * 5 * sizeof(float4);
@@ -778,11 +813,13 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	c->scene_in_lds = scene_bytes + 2 * stack_bytes <= 40 * 1024;                   // two stack planes when LDS-resident
 	c->trav_mode = (!flat.empty() && prim_bytes <= 40 * 1024) ? 2 : (c->scene_in_lds ? 1 : 0);
 	if (const char* e = getenv("JETPBRT_TRAVERSAL")) { int m = atoi(e); if (m == 0 || (m == 1 && c->scene_in_lds)) c->trav_mode = m; }   // experiments: force a lower mode
-	c->lds_bytes = c->trav_mode == 2 ? prim_bytes : (c->trav_mode == 1 ? 2 * stack_bytes + scene_bytes : stack_bytes);
+	c->lds_bytes = c->trav_mode == 2 ? prim_bytes + 128 : (c->trav_mode == 1 ? 2 * stack_bytes + scene_bytes : stack_bytes);
 	{
 		size_t tab = ((size_t)2 * s->n_lights + (size_t)4 * s->n_materials) * sizeof(float4) + (size_t)s->n_materials * sizeof(int) + 16;
 		c->tables_in_lds = tab <= 16 * 1024;
 		c->shade_lds_bytes = c->tables_in_lds ? tab + (c->scene_in_lds ? prims.size() * sizeof(float4) + meta.size() * sizeof(int4) : 0) : 0;
+		c->stage_nee = c->tables_in_lds && std::max(1, planes) <= 4;
+		if (c->stage_nee) c->shade_lds_bytes += 16 + (size_t)std::max(1, planes) * 2 * JP_BLOCK * sizeof(float4);
 	}
 	c->n_planes = std::max(1, planes);
 	c->has_null_material = hasNull;
@@ -894,9 +931,12 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 				}
 				{
 					Stamper t(c, CLS_SHADE);
-					if (c->tables_in_lds && c->scene_in_lds) hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(JP_BLOCK), c->shade_lds_bytes, c->stream, c->sv, c->q, rc, cur, c->d_cnt);
-					else if (c->tables_in_lds) hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(JP_BLOCK), c->shade_lds_bytes, c->stream, c->sv, c->q, rc, cur, c->d_cnt);
-					else hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(JP_BLOCK), 0, c->stream, c->sv, c->q, rc, cur, c->d_cnt);
+					const bool st = c->stage_nee;
+					#define JP_LAUNCH_SHADE(A, B, C) hipLaunchKernelGGL((k_shade<A, B, C>), dim3(grid), dim3(JP_BLOCK), c->shade_lds_bytes, c->stream, c->sv, c->q, rc, cur, c->d_cnt)
+					if (c->tables_in_lds && c->scene_in_lds) { if (st) JP_LAUNCH_SHADE(true, true, true); else JP_LAUNCH_SHADE(true, true, false); }
+					else if (c->tables_in_lds) { if (st) JP_LAUNCH_SHADE(true, false, true); else JP_LAUNCH_SHADE(true, false, false); }
+					else JP_LAUNCH_SHADE(false, false, false);
+					#undef JP_LAUNCH_SHADE
 				}
 				{
 					Stamper t(c, CLS_SHADOW);
