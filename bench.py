@@ -63,19 +63,23 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (n, n))
         n = world
     dist = None
+    backend = os.environ.get("JETPBRT_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 path on a 1-GPU box (ranks share the card)
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(1, ndev)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     W, H = args.width, args.height
     spp_total = args.spp * n
     be = scenes.build_cornell(scenes.HostBackend("bench"), W, H, lambert_only=not args.full_materials)
     scene = be.flatten()
-    ctx = jp.Context(local_rank)
+    ctx = jp.Context(dev)
     ctx.upload(scene)
     params = jp.render_params(W, H, spp_total, 5, 1234, band_rows=20, shard_index=rank, shard_count=n)
     film_dev = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if world > 1 else None
@@ -84,8 +88,12 @@ def main():
         if world == 1:
             return ctx.render(params)                      # jp_render: kernels + film download, blocking
         ctx.render_device(params, film_dev.data_ptr(), sync=True)
-        dist.reduce(film_dev, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI onto rank 0's film
-        return film_dev.cpu().numpy() if rank == 0 else None
+        if backend == "nccl":
+            dist.reduce(film_dev, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI onto rank 0's film
+            return film_dev.cpu().numpy() if rank == 0 else None
+        host = film_dev.cpu()                              # rehearsal backend: the same reduce on host tensors
+        dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+        return host.numpy() if rank == 0 else None
 
     def fence():
         ctx.synchronize()
@@ -104,7 +112,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     samples_per_step = W * H * spp_total
@@ -152,7 +160,7 @@ def main():
     # ---- parity sample + CPU baseline (rank 0, N = 1 only); oracle/ is the checker here, never the thing measured ----
     cpu = None
     parity = None
-    if rank == 0 and n == 1 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu and (n == 1 or os.environ.get("JETPBRT_BENCH_PARITY_ALL")):
         sys.path.insert(0, os.path.join(REPO, "tests"))
         import harness as Hn
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

@@ -122,6 +122,39 @@ SCENES = {
 }
 
 
+def build_random_scene(be, W, Hh, seed, n_tris=120, tmpdir=None):
+    """Random triangle soup + rectangles + spheres, every material kind, triangle / rectangle / sphere area lights and
+    a coloured environment -- the same call sequence on any backend."""
+    import tempfile
+    rng = np.random.default_rng(seed)
+    d = tmpdir or tempfile.mkdtemp(prefix="jp_rand_")
+    be.camera((0, 0, 9), (0, 0, -1), (0, 1, 0), 55.0, W, Hh)
+    be.envlight(tuple(float(v) for v in rng.uniform(0.0, 0.3, 3)))
+    mats = [be.mat_matte(tuple(rng.uniform(0.1, 0.9, 3))), be.mat_matte(tuple(rng.uniform(0.1, 0.9, 3))),
+            be.mat_metal(tuple(rng.uniform(0.1, 1.5, 3)), tuple(rng.uniform(0.1, 3.0, 3)), float(rng.uniform(0.05, 0.4)), float(rng.uniform(0.05, 0.4)), bool(rng.integers(0, 2))),
+            be.mat_plastic(tuple(rng.uniform(0.1, 0.6, 3)), tuple(rng.uniform(0.1, 0.4, 3)), float(rng.uniform(0.05, 0.5)), bool(rng.integers(0, 2))),
+            be.mat_glass(float(rng.uniform(1.2, 1.8)), (0.95, 0.95, 0.95), (0.9, 0.95, 0.9)), be.mat_mirror((0.85, 0.85, 0.9))]
+    # four soups with different materials
+    for m in range(4):
+        c = rng.uniform(-3, 3, (n_tris // 4, 1, 3)); v = (c + rng.normal(0, 0.7, (n_tris // 4, 3, 3))).reshape(-1, 3).astype(np.float32)
+        f = np.arange(v.shape[0]).reshape(-1, 3)
+        path = os.path.join(d, "soup_%d_%d.obj" % (seed, m))
+        scenes.write_obj(path, v, f)
+        be.mesh(path, bool(m & 1), bool(m & 2), (0, 0, -1.0 * m), 1.0, mats[m], None)
+    # a mesh light (two triangles), a rectangle light and a sphere light
+    lp = os.path.join(d, "light_%d.obj" % seed)
+    scenes.write_obj(lp, np.array([[-1, 3.9, -1], [1, 3.9, -1], [1, 3.9, 1], [-1, 3.9, 1]], np.float32), np.array([[0, 1, 2], [0, 2, 3]]))
+    be.mesh(lp, False, False, (0, 0, 0), 1.0, mats[0], tuple(rng.uniform(5, 20, 3)))
+    be.rect(scenes.AXIS_YZ, -1, 1, -2, 0, -4.0, False, mats[1], tuple(rng.uniform(2, 8, 3)))
+    be.sphere((2.5, 2.0, 1.0), 0.5, mats[0], tuple(rng.uniform(5, 15, 3)))
+    be.sphere((-1.5, -1.0, 1.5), 0.8, mats[4], None)
+    be.sphere((1.2, -1.5, 0.5), 0.6, mats[5], None)
+    be.rect(scenes.AXIS_XZ, -6, 6, -6, 6, -3.0, False, mats[1], None)
+    be.rect(scenes.AXIS_XY, -6, 6, -3, 5, -6.0, False, mats[3], None)
+    be.preprocess()
+    return be
+
+
 def libc_srand(seed=1):
     """the reference BVH draws its split axes from libc rand() (bvh.h:61); reset it so that the compiled
     reference and the restatement build the same tree."""

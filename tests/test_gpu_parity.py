@@ -237,3 +237,30 @@ def test_bunny_scene_full_bvh(H, gpu_ctx):
     assert l2(film, ref) < TOL_L2, l2(film, ref)
     c = gpu_ctx.counters()
     assert abs(c.closest_rays - cnt.closest_rays) <= max(8, cnt.closest_rays * 2e-4)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_scenes(H, gpu_ctx, tmp_path, seed):
+    """random triangle soups, rectangles, spheres, every material, triangle / rectangle / sphere lights, env light"""
+    W, Hh, spp = 96, 80, 8
+    hb = H.build_random_scene(H.scenes.HostBackend("r"), W, Hh, seed, n_tris=400, tmpdir=str(tmp_path))
+    sp = hb.flatten()
+    gpu_ctx.upload(sp)
+    p = H.jp.render_params(W, Hh, spp, 5, 5 + seed)
+    film = gpu_ctx.render(p)
+    ref, cnt = H.oracle_render(sp, p, 8)
+    assert np.isfinite(film).all()
+    assert l2(film, ref) < TOL_L2, l2(film, ref)
+    c = gpu_ctx.counters()
+    assert abs(c.closest_rays - cnt.closest_rays) <= max(8, cnt.closest_rays * 5e-4)
+    rng = np.random.default_rng(seed)
+    m = 50000
+    o = rng.uniform(-4, 4, (m, 3)).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    tmin = np.full(m, 0.001, np.float32); tmax = np.full(m, np.inf, np.float32)
+    hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
+    L = H.oracle_lib(); oh = L.jp_oracle_scene_new(sp)
+    ohit = np.zeros(m, np.int32); ot = np.zeros(m, np.float32); oprim = np.zeros(m, np.int32); onrm = np.zeros((m, 3), np.float32); opos = np.zeros((m, 3), np.float32)
+    L.jp_oracle_trace(oh, m, H.ptr(o), H.ptr(d), H.ptr(tmin), H.ptr(tmax), H.ptr(ohit), H.ptr(ot), H.ptr(oprim), H.ptr(onrm), H.ptr(opos))
+    L.jp_oracle_scene_free(oh)
+    assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)) and (prim == oprim).mean() > 0.9999

@@ -40,3 +40,19 @@ def test_bunny_mesh_resolution_sweep(H):
         H.libc_srand(1)
         fo, _ = H.oracle_render(hb.flatten(), H.jp.render_params(W, Hh, 2, 5, 1234, 1), 4)
         assert np.array_equal(fr.view(np.uint32), fo.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_scenes_live_reference(H, tmp_path, seed):
+    """random soups + all shape kinds as lights + all materials: the restatement stays bit-identical to the reference"""
+    W, Hh, spp = 40, 32, 4
+    H.libc_srand(1)
+    rb = H.build_random_scene(H.RefBackend("r"), W, Hh, seed, tmpdir=str(tmp_path))
+    hb = H.build_random_scene(H.scenes.HostBackend("r"), W, Hh, seed, tmpdir=str(tmp_path))
+    assert rb.num_primitives() == hb.num_primitives() and rb.num_lights() == hb.num_lights() == 5
+    for mode in (0, 1):
+        fr = rb.render(W, Hh, spp, 5, mode, 77, 4)
+        H.libc_srand(1)
+        fo, _ = H.oracle_render(hb.flatten(), H.jp.render_params(W, Hh, spp, 5, 77, mode), 4)
+        assert np.isfinite(fr).all()
+        assert np.array_equal(fr.view(np.uint32), fo.view(np.uint32)), float(np.abs(fr - fo).max())
