@@ -12,7 +12,7 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
-HIP_LIB_PATH = os.path.join(PKG_DIR, "csrc", "libjetpbrt_amd.so")
+HIP_LIB_PATH = os.environ.get("JETPBRT_AMD_LIB") or os.path.join(PKG_DIR, "csrc", "libjetpbrt_amd.so")   # env override: A/B of kernel builds
 HOST_LIB_PATH = os.path.join(PKG_DIR, "host", "libjetpbrt_host.so")
 
 JP_MAT_PARAM_STRIDE = 16
