@@ -129,13 +129,16 @@ def main():
     roof = None
     if rank == 0:
         survivors = max(0, c.closest_rays - c.samples)     # rays written by k_shade (every ray but the camera rays)
+        # (ms, launches, algorithmic bytes = SURVEY.md section 8d per-unit figure x units the class processes,
+        #  bytes attributed to the kernel that actually moves each record -- DESIGN.md section 6)
         cls = {
-            "k_extend": (c.extend_ms, c.extend_launches, B_EXTEND_PER_RAY * c.closest_rays),
-            "k_shade": (c.shade_ms, c.shade_launches, B_SHADE_PER_PATH_IN * c.closest_rays + B_SHADE_PER_SURVIVOR * survivors + B_SHADE_PER_SHADOW_RAY * c.shadow_rays),
-            "k_shadow": (c.shadow_ms, c.shadow_launches, B_SHADOW_PER_RAY * c.shadow_rays),
+            "k_extend": (c.extend_ms, c.extend_launches, B_PER_SEGMENT * c.closest_rays, B_EXTEND_PER_RAY * c.closest_rays),
+            "k_shade": (c.shade_ms, c.shade_launches, B_PER_SEGMENT * c.closest_rays,
+                        B_SHADE_PER_PATH_IN * c.closest_rays + B_SHADE_PER_SURVIVOR * survivors + B_SHADE_PER_SHADOW_RAY * c.shadow_rays),
+            "k_shadow": (c.shadow_ms, c.shadow_launches, B_PER_SHADOW * c.shadow_rays, B_SHADOW_PER_RAY * c.shadow_rays),
         }
         dom = max(cls, key=lambda k: cls[k][0])
-        ms, launches, nbytes = cls[dom]
+        ms, launches, nbytes, attributed = cls[dom]
         launches = max(1, launches)
         achieved = (nbytes / launches) / (ms / launches * 1e-3) / 1e9 if ms > 0 else 0.0
         bytes_per_sample = (B_PER_SEGMENT * c.closest_rays + B_PER_SHADOW * c.shadow_rays) / max(1, c.samples) + B_FILM_PER_PIXEL / spp_total
@@ -151,6 +154,8 @@ def main():
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launch_ms_avg": round(ms / launches, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(nbytes / launches),
+                "unit_bytes": B_PER_SHADOW if dom == "k_shadow" else B_PER_SEGMENT, "units_per_launch": int((c.shadow_rays if dom == "k_shadow" else c.closest_rays) / launches),
+                "attributed_bytes_per_launch": int(attributed / launches),
                 "class_ms": {k: round(v[0], 3) for k, v in cls.items()},
                 "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "segments_per_sample": round(c.closest_rays / max(1, c.samples), 3),
                                "shadow_rays_per_sample": round(c.shadow_rays / max(1, c.samples), 3),

@@ -128,24 +128,25 @@ __device__ __forceinline__ bool sph_hit(V3 c, float r, V3 o, V3 d, float tmin, f
 template <int kS, typename PrimPtr>
 __device__ __forceinline__ bool prim_hit(PrimPtr prims, int pi, V3 o, V3 d, float tmin, float& tmax)
 {
-	const float4 g3 = prims[kS * pi + 3];
+	// all four quads of the record are requested together (no load waits on the shape type): one memory latency per
+	// primitive instead of two
+	const float4 g0 = prims[kS * pi + 0], g1 = prims[kS * pi + 1], g2 = prims[kS * pi + 2], g3 = prims[kS * pi + 3];
 	const int type = __float_as_int(g3.w);
-	const float4 g0 = prims[kS * pi + 0];
-	if (type == JP_SHAPE_SPHERE) return sph_hit(xyz(g0), g0.w, o, d, tmin, tmax);
-	const float4 g1 = prims[kS * pi + 1], g2 = prims[kS * pi + 2];
 	if (type == JP_SHAPE_TRIANGLE) return tri_hit(xyz(g0), xyz(g1), xyz(g2), xyz(g3), o, d, tmin, tmax);
+	if (type == JP_SHAPE_SPHERE) return sph_hit(xyz(g0), g0.w, o, d, tmin, tmax);
 	return rect_hit(xyz(g0), xyz(g1), xyz(g2), mk(g0.w, g1.w, g2.w), xyz(g3), o, d, tmin, tmax);
 }
 
 // ---- BVH traversal (replaces FBVH_Node::Intersect bvh.h:94-103: ordered, early-out, any-hit for shadows) -------
 // Driver: one ray per lane.  `stack` is this thread's column of the LDS stack (entry k at stack[k * JP_BLOCK]).
-// "while-while" form: a lane walks interior nodes until it holds a leaf, then intersects the leaf.
-// kNear (closest-hit, shallow stacks): the far child's entry distance is pushed next to its reference (a second
-// stack plane at stack[(depth + k) * JP_BLOCK]) and a popped entry that starts beyond the current hit is dropped
-// without touching its node -- in a closed room the first leaf usually holds the final hit, so most of the stack
-// dies this way.  Returns the device primitive index of the accepted hit (-1: none); `tmax` = hit distance.
-template <bool kAnyHit, bool kNear, int kS, typename NodePtr, typename PrimPtr>
-__device__ __forceinline__ int traverse(NodePtr nodes, PrimPtr prims, V3 o, V3 d, float tmin, float& tmax, int* stack, int depth)
+// "while-while" form: a lane walks interior nodes until it holds a leaf, then intersects the leaf.  Both children's
+// slabs are tested from one 64-byte node with t = (b - o) * (1/d): relative error of a few ulp in t (the
+// fma(b, 1/d, -o/d) form would lose absolute accuracy for near-axis-parallel rays); boxes are padded at upload and
+// compared with 2e-6 slack, so our own topology may be tested more generously than the reference's boxes, never more
+// strictly than the geometry.  fminf/fmaxf drop the NaN of 0 * inf (ray lying in a slab plane).
+// Returns the device primitive index of the accepted hit (-1: none); `tmax` = hit distance.
+template <bool kAnyHit, int kS, typename NodePtr, typename PrimPtr>
+__device__ __forceinline__ int traverse(NodePtr nodes, PrimPtr prims, V3 o, V3 d, float tmin, float& tmax, int* stack)
 {
 	const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
 	int hit = -1, sp = 0, cur = 0;                                // node 0 is the root (always interior on the device)
@@ -165,42 +166,24 @@ __device__ __forceinline__ int traverse(NodePtr nodes, PrimPtr prims, V3 o, V3 d
 			const float rz0 = (n2.x - o.z) * iz, rz1 = (n2.w - o.z) * iz;
 			const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), tmin));
 			const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), tmax));
-			const bool hl = ln <= lf * 1.000002f, hr = rn <= rf * 1.000002f;   // slack >> rounding of the slab distances: never culls a true hit, also for zero-extent boxes
+			const bool hl = ln <= lf * 1.000002f, hr = rn <= rf * 1.000002f;
 			const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
 			if (hl && hr)
 			{
 				const bool leftFirst = kAnyHit ? true : (ln <= rn);
 				cur = leftFirst ? cl : cr;
-				stack[sp * JP_BLOCK] = leftFirst ? cr : cl;
-				if (kNear) stack[(depth + sp) * JP_BLOCK] = __float_as_int(leftFirst ? rn : ln);
-				sp++;
+				stack[sp * JP_BLOCK] = leftFirst ? cr : cl; sp++;
 			}
 			else if (hl) cur = cl;
 			else if (hr) cur = cr;
-			else
-			{
-				bool got = false;
-				while (sp > 0)
-				{
-					sp--;
-					if (kNear && __int_as_float(stack[(depth + sp) * JP_BLOCK]) * 0.999998f > tmax) continue;   // starts behind the hit
-					cur = stack[sp * JP_BLOCK]; got = true; break;
-				}
-				if (!got) { alive = false; break; }
-			}
+			else if (sp > 0) { sp--; cur = stack[sp * JP_BLOCK]; }
+			else { alive = false; break; }
 		}
 		if (!alive) break;
 		const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
 		for (int k = 0; k < count; k++)
 			if (prim_hit<kS>(prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) return hit; }
-		bool got = false;
-		while (sp > 0)
-		{
-			sp--;
-			if (kNear && __int_as_float(stack[(depth + sp) * JP_BLOCK]) * 0.999998f > tmax) continue;
-			cur = stack[sp * JP_BLOCK]; got = true; break;
-		}
-		if (!got) break;
+		if (sp > 0) { sp--; cur = stack[sp * JP_BLOCK]; } else break;
 	}
 	return hit;
 }

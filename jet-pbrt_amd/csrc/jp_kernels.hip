@@ -5,8 +5,8 @@
 // One batch = all pixels of this GPU's bands x S samples = P path slots (slot = s_local * NPIX + pixel).
 //   k_raygen   camera samples -> ray queue                         (sampler.h:148-155, camera.h:52-58)
 //   per bounce:
-//   k_extend   closest hit per queued ray: BVH traversal with an LDS stack (+ entry distances for early pops),
-//              scene in LDS when it fits
+//   k_extend   closest hit per queued ray: BVH traversal with an LDS stack, scene in LDS when it fits; tiny scenes use a
+//              flat wide node tested wave-uniformly
 //   k_shade    emission, material closure, NEE light samples -> shadow rays, BSDF sample, Russian roulette,
 //              surviving paths compacted (wave ballots + block prefix) into the next ray queue
 //   k_shadow   any-hit traversal per shadow entry, visible contributions added to the path's radiance in light order
@@ -128,13 +128,12 @@ __global__ void __launch_bounds__(JP_BLOCK) k_raygen(SceneView sc, Queues q, Ren
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// LDS layout of the traversal kernels: [stack: planes * depth * 256 ints][nodes][prims]; planes = 2 when the scene
-// is LDS-resident (references + entry distances), 1 otherwise
+// LDS layout of the traversal kernels: [stack: depth * 256 ints][nodes][prims]
 // ---------------------------------------------------------------------------------------------------------------------
 extern __shared__ float4 s_dyn[];      // 16-byte aligned base
 
 // kMode 0: BVH and primitives in global memory (L2 / Infinity Cache resident), one stack plane in LDS
-// kMode 1: BVH + primitives staged into LDS, two stack planes (references + entry distances)
+// kMode 1: BVH + primitives staged into LDS next to the stack
 // kMode 2: tiny scene: flat leaf list (uniform loads from global), primitives in LDS, no stack
 template <int kMode>
 struct SceneAccess;
@@ -143,7 +142,7 @@ template <> struct SceneAccess<0>
 	const float4 *nodes, *prims; int* stack; int depth;
 	__device__ __forceinline__ SceneAccess(const SceneView& sc, int depth_) : nodes(sc.nodes), prims(sc.prims), stack((int*)s_dyn + threadIdx.x), depth(depth_) {}
 	template <bool kAnyHit> __device__ __forceinline__ int trace(const SceneView&, V3 o, V3 d, float tmin, float& tmax) const
-	{ return traverse<kAnyHit, false, 4>(nodes, prims, o, d, tmin, tmax, stack, depth); }
+	{ return traverse<kAnyHit, 4>(nodes, prims, o, d, tmin, tmax, stack); }
 };
 template <> struct SceneAccess<1>
 {
@@ -151,14 +150,14 @@ template <> struct SceneAccess<1>
 	__device__ __forceinline__ SceneAccess(const SceneView& sc, int depth_) : depth(depth_)
 	{
 		stack = (int*)s_dyn + threadIdx.x;
-		nodes = s_dyn + (2 * depth * JP_BLOCK) / 4;
+		nodes = s_dyn + (depth * JP_BLOCK) / 4;
 		prims = nodes + 5 * sc.n_nodes;              // 80-byte record stride in LDS (bank spreading), 64 bytes used
 		for (int i = threadIdx.x; i < 4 * sc.n_nodes; i += JP_BLOCK) nodes[5 * (i >> 2) + (i & 3)] = sc.nodes[i];
 		for (int i = threadIdx.x; i < 4 * sc.n_prims; i += JP_BLOCK) prims[5 * (i >> 2) + (i & 3)] = sc.prims[i];
 		__syncthreads();
 	}
 	template <bool kAnyHit> __device__ __forceinline__ int trace(const SceneView&, V3 o, V3 d, float tmin, float& tmax) const
-	{ return traverse<kAnyHit, !kAnyHit, 5>(nodes, prims, o, d, tmin, tmax, stack, depth); }
+	{ return traverse<kAnyHit, 5>(nodes, prims, o, d, tmin, tmax, stack); }
 };
 template <> struct SceneAccess<2>
 {
@@ -424,7 +423,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 // reference's order and the film is run-to-run deterministic (no float atomics).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int kMode>
-__global__ void __launch_bounds__(JP_BLOCK) k_shadow(SceneView sc, Queues q, RenderConst rc, int depth, DevCounters* cnt)
+__global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow(SceneView sc, Queues q, RenderConst rc, int depth, DevCounters* cnt)
 {
 	SceneAccess<kMode> acc(sc, depth);
 	const unsigned int b = blockIdx.x, E = q.blk_sh[b], rbase = b * q.R;
@@ -810,10 +809,10 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	size_t scene_bytes = (nodes.size() + prims.size()) / 4 * 5 * sizeof(float4);   // 80-byte LDS record stride
 	size_t prim_bytes = prims.size() / 4 * 5 * sizeof(float4);
 	size_t stack_bytes = (size_t)c->stack_depth * JP_BLOCK * sizeof(int);
-	c->scene_in_lds = scene_bytes + 2 * stack_bytes <= 40 * 1024;                   // two stack planes when LDS-resident
+	c->scene_in_lds = scene_bytes + stack_bytes <= 40 * 1024;
 	c->trav_mode = (!flat.empty() && prim_bytes <= 40 * 1024) ? 2 : (c->scene_in_lds ? 1 : 0);
 	if (const char* e = getenv("JETPBRT_TRAVERSAL")) { int m = atoi(e); if (m == 0 || (m == 1 && c->scene_in_lds)) c->trav_mode = m; }   // experiments: force a lower mode
-	c->lds_bytes = c->trav_mode == 2 ? prim_bytes + 128 : (c->trav_mode == 1 ? 2 * stack_bytes + scene_bytes : stack_bytes);
+	c->lds_bytes = c->trav_mode == 2 ? prim_bytes + 128 : (c->trav_mode == 1 ? stack_bytes + scene_bytes : stack_bytes);
 	{
 		size_t tab = ((size_t)2 * s->n_lights + (size_t)4 * s->n_materials) * sizeof(float4) + (size_t)s->n_materials * sizeof(int) + 16;
 		c->tables_in_lds = tab <= 16 * 1024;
