@@ -89,6 +89,24 @@ __device__ __forceinline__ unsigned int block_prefix(bool flag, unsigned int* s_
 	return base + prefix;
 }
 
+// two flags at once (counts packed 16:16), ONE barrier: s_tmp2 is double-buffered by `phase`, so the next call's
+// writes cannot race with this call's reads.  Every thread of the block must call it.
+__device__ __forceinline__ void block_prefix2(bool fa, bool fb, unsigned int* s_tmp2 /* [2][JP_BLOCK/64] */, unsigned int phase,
+                                             unsigned int& pa, unsigned int& ta, unsigned int& pb, unsigned int& tb)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	const unsigned long long ma = __ballot(fa), mb = __ballot(fb);
+	unsigned int* t = s_tmp2 + (phase & 1u) * (JP_BLOCK / 64);
+	if (lane == 0) t[wave] = (unsigned int)__popcll(ma) | ((unsigned int)__popcll(mb) << 16);
+	__syncthreads();
+	unsigned int base = 0, tot = 0;
+	#pragma unroll
+	for (int w = 0; w < JP_BLOCK / 64; w++) { const unsigned int v = t[w]; if (w < wave) base += v; tot += v; }
+	pa = (base & 0xffffu) + (unsigned int)__popcll(ma & lt); ta = tot & 0xffffu;
+	pb = (base >> 16) + (unsigned int)__popcll(mb & lt); tb = tot >> 16;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // k_raygen: FSampler::GetCameraSample (sampler.h:148-155) + FCamera::GenerateRay (camera.h:52-58).
 // Block b takes the 256-slot chunks b, b+G, b+2G, ... (an even sample of the image, so every region ages alike) and
@@ -213,6 +231,8 @@ template <bool kTab, bool kPrims, bool kStage>
 __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, RenderConst rc, int cur, DevCounters* cnt)
 {
 	__shared__ unsigned int s_tmp[JP_BLOCK / 64];
+	__shared__ unsigned int s_tmp2[2 * (JP_BLOCK / 64)];
+	unsigned int chunk = 0;
 	float4* s_lights = s_dyn;
 	float4* s_mats = s_lights + 2 * sc.n_lights;
 	float4* s_prims = s_mats + 4 * sc.n_mats;
@@ -360,19 +380,6 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				if (!kStage) q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
 			}
 		}
-		if (kStage)
-		{
-			unsigned int tot_sh; qs = rbase + run_sh + block_prefix(k > 0, s_tmp, tot_sh); run_sh += tot_sh;
-			if (k > 0)
-			{
-				q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
-				for (int kk = 0; kk < k; kk++)
-				{
-					q.sh_d[(size_t)kk * q.cap + qs] = s_stage[(2 * kk) * JP_BLOCK];
-					q.sh_c[(size_t)kk * q.cap + qs] = s_stage[(2 * kk + 1) * JP_BLOCK];
-				}
-			}
-		}
 		if (shaded)
 		{
 			// ---- BSDF sample (integrator.cc:375-379) ----
@@ -400,8 +407,25 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				nd = bs.wi; nbounce = bounce + 1;
 			}
 		}
-		// ---- compact survivors into the next ray queue ----
-		unsigned int tot_q; const unsigned int j = rbase + run_q + block_prefix(alive, s_tmp, tot_q); run_q += tot_q;
+		// ---- compact survivors into the next ray queue (and, when staged, the shadow entries): one barrier per chunk ----
+		unsigned int j;
+		if (kStage)
+		{
+			unsigned int pq, tq, ps, ts;
+			block_prefix2(alive, k > 0, s_tmp2, chunk++, pq, tq, ps, ts);
+			j = rbase + run_q + pq; run_q += tq;
+			qs = rbase + run_sh + ps; run_sh += ts;
+			if (k > 0)
+			{
+				q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
+				for (int kk = 0; kk < k; kk++)
+				{
+					q.sh_d[(size_t)kk * q.cap + qs] = s_stage[(2 * kk) * JP_BLOCK];
+					q.sh_c[(size_t)kk * q.cap + qs] = s_stage[(2 * kk + 1) * JP_BLOCK];
+				}
+			}
+		}
+		else { unsigned int tot_q; j = rbase + run_q + block_prefix(alive, s_tmp, tot_q); run_q += tot_q; }
 		if (alive)
 		{
 			q.ray_o[nxt][j] = make_float4(p.x, p.y, p.z, __int_as_float(slot));       // SpawnRay shape.h:61-64
@@ -937,6 +961,7 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 					else JP_LAUNCH_SHADE(false, false, false);
 					#undef JP_LAUNCH_SHADE
 				}
+				if (it < rp->max_depth || c->has_null_material)                 // at bounce == maxDepth Li() breaks before the NEE (integrator.cc:340-343)
 				{
 					Stamper t(c, CLS_SHADOW);
 					if (c->trav_mode == 2) hipLaunchKernelGGL(k_shadow<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
