@@ -14,6 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 HIP_LIB_PATH = os.environ.get("JETPBRT_AMD_LIB") or os.path.join(PKG_DIR, "csrc", "libjetpbrt_amd.so")   # env override: A/B of kernel builds
 HOST_LIB_PATH = os.path.join(PKG_DIR, "host", "libjetpbrt_host.so")
+CLI_PATH = os.path.join(PKG_DIR, "host", "jetpbrt")
 
 JP_MAT_PARAM_STRIDE = 16
 JP_SAMPLER_STOCK_MT19937, JP_SAMPLER_COUNTER = 0, 1
@@ -99,6 +100,7 @@ def host_lib():
         L.jp_host_flatten.argtypes = [C.c_void_p]
         L.jp_host_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.POINTER(JpCounters)]
+        L.jp_host_save_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
         _host = L
     return _host
 

@@ -92,4 +92,12 @@ int jp_host_render(void* h, int W, int H, int spp, int maxdepth, unsigned seed, 
 	return JP_OK;
 }
 
+// FFilm::SaveAsImage on an rgb buffer (type 0 PPM, 1 BMP, 2 HDR): returns 1 on success
+int jp_host_save_image(const float* rgb, int W, int H, const char* filename, int type)
+{
+	FFilm film(W, H);
+	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const float* p = rgb + 3 * ((size_t)y * W + x); film(x, y) = FColor(p[0], p[1], p[2]); }
+	return film.SaveAsImage(filename, type == 0 ? EImageType::PPM : (type == 2 ? EImageType::HDR : EImageType::BMP)) ? 1 : 0;
+}
+
 } // extern "C"

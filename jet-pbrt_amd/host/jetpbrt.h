@@ -196,7 +196,12 @@ public:
 	FVector3 pos, front, right, up; FVector2 resolution;
 };
 
-class FFilm                                                      // film.h:27-94 (pixel store only; image writers are out of scope)
+enum class EImageType { PPM, BMP, HDR };                         // film.h:15-20
+
+inline Float Clamp01(Float x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }                                   // film.h:22
+inline uint8_t gamma_encoding(Float x) { return (uint8_t)(std::pow(Clamp01(x), (Float)(1 / 2.2)) * 255.0); }   // film.h:24
+
+class FFilm                                                      // film.h:27-94
 {
 public:
 	FFilm(int w, int h) : width(w), height(h), pixels((size_t)w * h) {}
@@ -205,6 +210,8 @@ public:
 	FColor& operator()(int x, int y) { return pixels[(size_t)width * y + x]; }
 	void AddColor(int x, int y, const FColor& c) { FColor& p = (*this)(x, y); p.r += c.r; p.g += c.g; p.b += c.b; }
 	void Clear() { for (auto& p : pixels) p = FColor(); }
+	// the output step right after the hot path (main.cc:160): <filename>.ppm/.bmp/.hdr, gamma 1/2.2 for the 8-bit formats
+	bool SaveAsImage(const std::string& filename, EImageType imgType) const;
 	int width, height; std::vector<FColor> pixels;
 };
 

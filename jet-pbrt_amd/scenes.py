@@ -311,3 +311,20 @@ def build_misc(be, width, height):
         b.rect(AXIS_XY, 150, 400, 100, 400, 500, False, -1, None)          # null material: rays pass through
     be_ = build_cornell(be, width, height, lambert_only=False, extras=extras, env=(0.05, 0.08, 0.2))
     return be_
+
+
+def export_reference_layout(root, n_lon=187, n_lat=188):
+    """Writes the synthetic assets in the directory layout main.cc expects (scene/cornellbox/*.obj, scene/bunny/bunny.obj)
+    for the command-line front end (jet-pbrt_amd/host/jetpbrt --assets ROOT)."""
+    os.makedirs(os.path.join(root, "cornellbox"), exist_ok=True)
+    os.makedirs(os.path.join(root, "bunny"), exist_ok=True)
+    for name, quads in CORNELL.items():
+        quads_to_obj(os.path.join(root, "cornellbox", name + ".obj"), quads)
+    v, f = bunny_mesh(n_lon, n_lat)
+    write_obj(os.path.join(root, "bunny", "bunny.obj"), v, f)
+    return root
+
+
+if __name__ == "__main__":
+    import sys
+    print(export_reference_layout(sys.argv[1] if len(sys.argv) > 1 else "scene"))

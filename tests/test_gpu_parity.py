@@ -264,3 +264,22 @@ def test_random_scenes(H, gpu_ctx, tmp_path, seed):
     L.jp_oracle_trace(oh, m, H.ptr(o), H.ptr(d), H.ptr(tmin), H.ptr(tmax), H.ptr(ohit), H.ptr(ot), H.ptr(oprim), H.ptr(onrm), H.ptr(opos))
     L.jp_oracle_scene_free(oh)
     assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)) and (prim == oprim).mean() > 0.9999
+
+
+def test_cli_renders_cornell_to_bmp(H, gpu_ctx, tmp_path):
+    """the reference's command line (`pbrt sceneid spp`, main.cc:113-163) end to end: scene script in C++, GPU render, BMP"""
+    import subprocess
+    root = H.scenes.export_reference_layout(str(tmp_path / "scene"), 24, 16)
+    out = str(tmp_path / "cornell")
+    r = subprocess.run([H.jp.CLI_PATH, "0", "8", "64", "48", "--assets", root, "--out", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = open(out + ".bmp", "rb").read()
+    assert raw[:2] == b"BM" and len(raw) == 54 + 64 * 3 * 48
+    img = np.frombuffer(raw[54:], np.uint8).reshape(48, 64, 3)[::-1, :, ::-1]
+    hb, sp = _scene(H, "cornell", 64, 48)
+    gpu_ctx.upload(sp)
+    film = gpu_ctx.render(H.jp.render_params(64, 48, 8, 5, 1234))           # FRandomSampler -> counter stream, seed 1234
+    enc = (np.power(np.clip(film, 0, 1), np.float32(1 / 2.2)).astype(np.float64) * 255.0).astype(np.uint8)
+    assert np.abs(img.astype(int) - enc.astype(int)).max() <= 1
+    r = subprocess.run([H.jp.CLI_PATH, "1", "2", "64", "48", "--assets", root, "--out", out + "_b", "--format", "hdr"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and os.path.getsize(out + "_b.hdr") > 64 * 48 * 4

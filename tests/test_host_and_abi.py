@@ -134,3 +134,50 @@ def test_create_context_without_gpu_fails_loudly(H):
     with pytest.raises(H.jp.JetPbrtError) as e:
         H.jp.Context(0)
     assert "no HIP device" in str(e.value) or "status -2" in str(e.value)
+
+
+def test_film_writers(H, tmp_path):
+    """FFilm::SaveAsImage (film.cc:11-188 behaviour, format rules applied properly): PPM P3 with decimal samples, BMP with
+    4-byte row padding for a width with width*3 % 4 != 0, Radiance HDR; gamma_encoding = uint8(pow(clamp01(x), 1/2.2) * 255)."""
+    W, Hh = 5, 3                                   # 15 bytes per row -> padded to 16
+    rng = np.random.default_rng(1)
+    rgb = rng.uniform(-0.2, 1.3, (Hh, W, 3)).astype(np.float32); rgb[0, 0] = (0, 0, 0); rgb[1, 2] = (1e-35, 0, 0)
+    rgb[..., 1:] = np.abs(rgb[..., 1:]); rgb[:, 1:, 0] = np.abs(rgb[:, 1:, 0]); rgb[2, 0, 0] = -0.1     # one negative channel: clamps to 0 in the 8-bit formats
+    L = H.jp.host_lib()
+    base = str(tmp_path / "img")
+    for t in (0, 1, 2):
+        assert L.jp_host_save_image(rgb.ctypes.data, W, Hh, base.encode(), t) == 1
+    enc = (np.power(np.clip(rgb.astype(np.float32), 0, 1), np.float32(1 / 2.2)).astype(np.float64) * 255.0).astype(np.uint8)
+    tok = open(base + ".ppm").read().split()
+    assert tok[:4] == ["P3", str(W), str(Hh), "255"]
+    ppm = np.array(tok[4:], int).reshape(Hh, W, 3)
+    assert np.abs(ppm - enc.astype(int)).max() <= 1          # pow() last-bit differences only
+    raw = open(base + ".bmp", "rb").read()
+    assert raw[:2] == b"BM" and int.from_bytes(raw[2:6], "little") == len(raw) == 54 + 16 * Hh
+    assert int.from_bytes(raw[18:22], "little") == W and int.from_bytes(raw[22:26], "little") == Hh and int.from_bytes(raw[28:30], "little") == 24
+    body = np.frombuffer(raw[54:], np.uint8).reshape(Hh, 16)[::-1, : 3 * W].reshape(Hh, W, 3)[..., ::-1]   # bottom-up, BGR
+    assert np.array_equal(body, ppm.astype(np.uint8))
+    hdr = open(base + ".hdr", "rb").read()
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 3 +X 5\n"
+    assert hdr.startswith(head) and len(hdr) == len(head) + 4 * W * Hh
+    px = np.frombuffer(hdr[len(head):], np.uint8).reshape(Hh, W, 4)
+    assert tuple(px[0, 0]) == (0, 0, 0, 0) and tuple(px[1, 2]) == (0, 0, 0, 0)
+    e = px[..., 3].astype(int) - 128 - 8
+    dec = px[..., :3].astype(np.float64) * np.exp2(e)[..., None]
+    pos = np.clip(rgb, 0, None)
+    live = (rgb.max(-1) >= 1e-32) & (rgb.min(-1) >= 0)
+    assert np.abs(dec[live] - pos[live]).max() <= rgb.max() / 128 + 1e-6
+
+
+def test_cli_usage_and_no_gpu_behaviour(H, tmp_path):
+    """`jetpbrt` mirrors main.cc:113-163: no arguments -> usage line, exit 0; without a GPU it must fail loudly and write nothing"""
+    import subprocess
+    r = subprocess.run([H.jp.CLI_PATH], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and "sceneid" in r.stderr
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    root = H.scenes.export_reference_layout(str(tmp_path / "scene"), 12, 8)
+    r = subprocess.run([H.jp.CLI_PATH, "0", "1", "16", "16", "--assets", root, "--out", str(tmp_path / "o")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 3 and not (tmp_path / "o.bmp").exists()
+    assert "no HIP device" in r.stderr or "not available" in r.stderr
