@@ -283,3 +283,41 @@ def test_cli_renders_cornell_to_bmp(H, gpu_ctx, tmp_path):
     assert np.abs(img.astype(int) - enc.astype(int)).max() <= 1
     r = subprocess.run([H.jp.CLI_PATH, "1", "2", "64", "48", "--assets", root, "--out", out + "_b", "--format", "hdr"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0 and os.path.getsize(out + "_b.hdr") > 64 * 48 * 4
+
+
+def test_batching_and_region_layout_do_not_change_the_film(H, gpu_ctx, monkeypatch):
+    """the film must not depend on how samples are cut into batches or paths into workgroup regions"""
+    W, Hh, spp = 160, 100, 24
+    hb, sp = _scene(H, "cornell", W, Hh)
+    gpu_ctx.upload(sp)
+    p = H.jp.render_params(W, Hh, spp, 5, 21)
+    base = gpu_ctx.render(p)
+    for slots, bpc in ((W * Hh * 5, "3"), (W * Hh, "16"), (W * Hh * 24, "1"), (W * Hh * 7, "64")):
+        monkeypatch.setenv("JETPBRT_MAX_SLOTS", str(slots))
+        ctx2 = H.jp.Context(0)
+        try:
+            monkeypatch.setenv("JETPBRT_BLOCKS_PER_CU", bpc)
+            ctx3 = H.jp.Context(0)                       # blocks-per-CU is read at context creation
+            ctx3.upload(sp)
+            other = ctx3.render(p)
+            ctx3.close()
+        finally:
+            ctx2.close()
+        assert np.array_equal(other.view(np.uint32), base.view(np.uint32)), (slots, bpc)
+    monkeypatch.delenv("JETPBRT_MAX_SLOTS"); monkeypatch.delenv("JETPBRT_BLOCKS_PER_CU")
+
+
+def test_large_film_and_deep_paths(H, gpu_ctx):
+    """1920x1080 (configs[4] film size) at 1 spp and maxDepth 12 on the coverage scene: whole bands against the oracle"""
+    W, Hh = 1920, 1080
+    hb, sp = _scene(H, "misc", W, Hh)
+    gpu_ctx.upload(sp)
+    film = gpu_ctx.render(H.jp.render_params(W, Hh, 1, 12, 3))
+    nb = (Hh + 19) // 20
+    tot = 0.0; npx = 0
+    for b in (0, 27, 53):
+        p = H.jp.render_params(W, Hh, 1, 12, 3, shard_index=b, shard_count=nb)
+        ref, _ = H.oracle_render(sp, p, 8)
+        y0, y1 = b * 20, min(Hh, b * 20 + 20)
+        d = np.sqrt(((film[y0:y1] - ref[y0:y1]) ** 2).sum(-1)); tot += d.sum(); npx += d.size
+    assert tot / npx < 2e-4, tot / npx                     # 1 spp: a single flipped path moves a pixel by O(1); still tiny on average
