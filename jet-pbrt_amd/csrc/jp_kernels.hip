@@ -164,6 +164,7 @@ extern __shared__ float4 s_dyn[];      // 16-byte aligned base
 // kMode 0: BVH and primitives in global memory (L2 / Infinity Cache resident), one stack plane in LDS
 // kMode 1: BVH + primitives staged into LDS next to the stack
 // kMode 2: tiny scene: flat leaf list (uniform loads from global), primitives in LDS, no stack
+// kMode 3: large scene: 8-wide quantised BVH in global memory, (group, hits) stack pairs in LDS
 template <int kMode>
 struct SceneAccess;
 template <> struct SceneAccess<0>
@@ -201,6 +202,14 @@ template <> struct SceneAccess<2>
 	}
 	template <bool kAnyHit> __device__ __forceinline__ int trace(const SceneView& sc, V3 o, V3 d, float tmin, float& tmax) const
 	{ return traverse_flat<kAnyHit, 5>(sc.flat, sc.n_flat, leaf, prims, o, d, tmin, tmax); }
+};
+
+template <> struct SceneAccess<3>
+{
+	const float4* prims; unsigned int* stack;
+	__device__ __forceinline__ SceneAccess(const SceneView& sc, int) : prims(sc.prims), stack((unsigned int*)s_dyn + threadIdx.x) {}
+	template <bool kAnyHit> __device__ __forceinline__ int trace(const SceneView& sc, V3 o, V3 d, float tmin, float& tmax) const
+	{ return traverse_wide<kAnyHit>(sc.wide, prims, o, d, tmin, tmax, stack); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -561,8 +570,8 @@ struct JpContext
 	int n_cus = 256;
 	// scene
 	bool have_scene = false;
-	SceneView sv; int stack_depth = 1; bool scene_in_lds = false; size_t lds_bytes = 0;
-	void *d_flat = nullptr, *d_flat_leaf = nullptr; int trav_mode = 0;
+	SceneView sv; int stack_depth = 1; bool scene_in_lds = false; size_t lds_bytes = 0, lds_bytes_shadow = 0;
+	void *d_flat = nullptr, *d_flat_leaf = nullptr, *d_wide = nullptr; int trav_mode = 0;
 	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr;
 	int n_planes = 1; bool has_null_material = false;
 	bool tables_in_lds = false, stage_nee = false; size_t shade_lds_bytes = 0;
@@ -583,7 +592,7 @@ struct JpContext
 
 static void free_scene(JpContext* c)
 {
-	void** ps[] = { &c->d_flat, &c->d_flat_leaf, &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights };
+	void** ps[] = { &c->d_flat, &c->d_flat_leaf, &c->d_wide, &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights };
 	for (void** p : ps) { if (*p) hipFree(*p); *p = nullptr; }
 	c->have_scene = false;
 }
@@ -720,35 +729,159 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 			b[a] = lo - e; b[3 + a] = hi + e;
 		}
 	};
+	auto emit_prim = [&](int p) -> int {
+		const int dev = (int)meta.size(); devPrimOf[p] = dev;
+		int t = s->prim_shape_type[p], i = s->prim_shape_index[p];
+		float4 g[4] = { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) };
+		if (t == JP_SHAPE_TRIANGLE)
+		{
+			g[0] = make_float4(s->tri_p0[3 * i], s->tri_p0[3 * i + 1], s->tri_p0[3 * i + 2], 0); g[1] = make_float4(s->tri_p1[3 * i], s->tri_p1[3 * i + 1], s->tri_p1[3 * i + 2], 0);
+			g[2] = make_float4(s->tri_p2[3 * i], s->tri_p2[3 * i + 1], s->tri_p2[3 * i + 2], 0); g[3] = make_float4(s->tri_n[3 * i], s->tri_n[3 * i + 1], s->tri_n[3 * i + 2], 0);
+		}
+		else if (t == JP_SHAPE_RECTANGLE)
+		{
+			g[0] = make_float4(s->rect_p0[3 * i], s->rect_p0[3 * i + 1], s->rect_p0[3 * i + 2], s->rect_p3[3 * i]);
+			g[1] = make_float4(s->rect_p1[3 * i], s->rect_p1[3 * i + 1], s->rect_p1[3 * i + 2], s->rect_p3[3 * i + 1]);
+			g[2] = make_float4(s->rect_p2[3 * i], s->rect_p2[3 * i + 1], s->rect_p2[3 * i + 2], s->rect_p3[3 * i + 2]);
+			g[3] = make_float4(s->rect_n[3 * i], s->rect_n[3 * i + 1], s->rect_n[3 * i + 2], 0);
+		}
+		else g[0] = make_float4(s->sph_center[3 * i], s->sph_center[3 * i + 1], s->sph_center[3 * i + 2], s->sph_radius[i]);
+		int tb = t; std::memcpy(&g[3].w, &tb, 4);
+		for (int j = 0; j < 4; j++) prims.push_back(g[j]);
+		int4 m; m.x = p; m.y = s->prim_material[p]; m.z = s->prim_light[p]; m.w = t; meta.push_back(m);
+		return dev;
+	};
 	auto emit_leaf = [&](int n) -> int {
 		int first = -s->bvh_left[n] - 1, cnt = s->bvh_right[n];
-		int dfirst = (int)meta.size();
-		for (int k = 0; k < cnt; k++)
-		{
-			int p = s->bvh_prim_index[first + k]; devPrimOf[p] = (int)meta.size();
-			int t = s->prim_shape_type[p], i = s->prim_shape_index[p];
-			float4 g[4] = { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) };
-			if (t == JP_SHAPE_TRIANGLE)
-			{
-				g[0] = make_float4(s->tri_p0[3 * i], s->tri_p0[3 * i + 1], s->tri_p0[3 * i + 2], 0); g[1] = make_float4(s->tri_p1[3 * i], s->tri_p1[3 * i + 1], s->tri_p1[3 * i + 2], 0);
-				g[2] = make_float4(s->tri_p2[3 * i], s->tri_p2[3 * i + 1], s->tri_p2[3 * i + 2], 0); g[3] = make_float4(s->tri_n[3 * i], s->tri_n[3 * i + 1], s->tri_n[3 * i + 2], 0);
-			}
-			else if (t == JP_SHAPE_RECTANGLE)
-			{
-				g[0] = make_float4(s->rect_p0[3 * i], s->rect_p0[3 * i + 1], s->rect_p0[3 * i + 2], s->rect_p3[3 * i]);
-				g[1] = make_float4(s->rect_p1[3 * i], s->rect_p1[3 * i + 1], s->rect_p1[3 * i + 2], s->rect_p3[3 * i + 1]);
-				g[2] = make_float4(s->rect_p2[3 * i], s->rect_p2[3 * i + 1], s->rect_p2[3 * i + 2], s->rect_p3[3 * i + 2]);
-				g[3] = make_float4(s->rect_n[3 * i], s->rect_n[3 * i + 1], s->rect_n[3 * i + 2], 0);
-			}
-			else g[0] = make_float4(s->sph_center[3 * i], s->sph_center[3 * i + 1], s->sph_center[3 * i + 2], s->sph_radius[i]);
-			int tb = t; std::memcpy(&g[3].w, &tb, 4);
-			for (int j = 0; j < 4; j++) prims.push_back(g[j]);
-			int4 m; m.x = p; m.y = s->prim_material[p]; m.z = s->prim_light[p]; m.w = t; meta.push_back(m);
-		}
+		int dfirst = devPrimOf[s->bvh_prim_index[first]];                    // already placed by the wide-tree pass?
+		if (dfirst < 0) { dfirst = (int)meta.size(); for (int k = 0; k < cnt; k++) emit_prim(s->bvh_prim_index[first + k]); }
 		return -(((dfirst << 4) | (cnt - 1)) + 1);
 	};
-	// interior nodes get device indices in DFS order
-	std::vector<int> order; { std::vector<int> st; st.push_back(0); while (!st.empty()) { int n = st.back(); st.pop_back(); if (s->bvh_left[n] < 0) continue; hostToDevNode[n] = (int)order.size(); order.push_back(n); st.push_back(s->bvh_right[n]); st.push_back(s->bvh_left[n]); } }
+
+	// ---- large scenes: collapse the binary tree into 8-wide nodes with quantised child boxes (traverse_wide) ----
+	int nleaves_total = 0; for (int n = 0; n < s->n_bvh_nodes; n++) if (seen[n] && s->bvh_left[n] < 0) nleaves_total++;
+	std::vector<uint32_t> wide; int wide_height = 0;
+	bool use_wide = nleaves_total > 32 && s->bvh_left[0] >= 0;
+	{
+		size_t est = ((size_t)s->n_bvh_nodes + (size_t)s->n_primitives) * 80;                            // LDS-resident scenes keep the binary tree
+		if (est + (size_t)(height + 2) * JP_BLOCK * sizeof(int) <= 40 * 1024) use_wide = false;
+		if (const char* e = getenv("JETPBRT_TRAVERSAL")) { int m = atoi(e); if (m == 3 && s->bvh_left[0] >= 0) use_wide = true; else if (m >= 0 && m <= 2) use_wide = false; }
+	}
+	if (use_wide)
+	{
+		struct Child { int node; int first, cnt, leaf_first, leaf_cnt; float b[6]; };   // node >= 0: inner (binary node index); else a chunk of <= 3 primitives of one binary leaf
+		struct Item { int bnode; uint32_t widx; int depth; };
+		auto area = [](const float* b) { float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2]; return dx * dy + dy * dz + dz * dx; };
+		std::vector<Item> queue; queue.push_back({ 0, 0u, 1 });
+		wide.assign(20, 0u);
+		bool ok = true;
+		for (size_t qi = 0; qi < queue.size() && ok; qi++)
+		{
+			const Item it = queue[qi];
+			wide_height = std::max(wide_height, it.depth);
+			// gather up to 8 child slots: open the inner child with the largest box while the slots allow it
+			std::vector<Child> ch;
+			auto add = [&](int n) {
+				float b[6]; pad_box(n, b);
+				if (s->bvh_left[n] >= 0) { Child c; c.node = n; c.first = c.cnt = c.leaf_first = c.leaf_cnt = 0; std::memcpy(c.b, b, sizeof(b)); ch.push_back(c); }
+				else
+				{
+					int first = -s->bvh_left[n] - 1, cnt = s->bvh_right[n];
+					for (int k = 0; k < cnt; k += 3) { Child c; c.node = -1; c.first = first + k; c.cnt = std::min(3, cnt - k); c.leaf_first = first; c.leaf_cnt = cnt; std::memcpy(c.b, b, sizeof(b)); ch.push_back(c); }
+				}
+			};
+			auto slots_of = [&](int n) { return s->bvh_left[n] >= 0 ? 1 : (s->bvh_right[n] + 2) / 3; };
+			add(s->bvh_left[it.bnode]); add(s->bvh_right[it.bnode]);
+			for (;;)
+			{
+				int best = -1; float bestA = -1.f;
+				for (size_t k = 0; k < ch.size(); k++)
+					if (ch[k].node >= 0)
+					{
+						int need = (int)ch.size() - 1 + slots_of(s->bvh_left[ch[k].node]) + slots_of(s->bvh_right[ch[k].node]);
+						if (need <= 8 && area(ch[k].b) > bestA) { bestA = area(ch[k].b); best = (int)k; }
+					}
+				if (best < 0) break;
+				const int n = ch[best].node; ch.erase(ch.begin() + best);
+				add(s->bvh_left[n]); add(s->bvh_right[n]);
+			}
+			if (ch.size() > 8) { ok = false; break; }
+			// node box, scale exponents
+			float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+			for (const Child& c : ch) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], c.b[a]); hi[a] = std::max(hi[a], c.b[3 + a]); }
+			int eb[3]; float sc3[3];
+			for (int a = 0; a < 3; a++)
+			{
+				int e = (int)std::ceil(std::log2(std::max((hi[a] - lo[a]) / 255.f, 1e-30f)));
+				e = std::max(-120, std::min(120, e));
+				eb[a] = e + 127; sc3[a] = std::ldexp(1.0f, e);
+			}
+			// slots: the three bits of a slot say on which side of the node centre the child lies (greedy assignment)
+			int slotOf[8]; bool used[8] = { false, false, false, false, false, false, false, false };
+			{
+				struct Cand { float score; int child, slot; };
+				std::vector<Cand> cands;
+				for (size_t k = 0; k < ch.size(); k++) for (int sl = 0; sl < 8; sl++)
+				{
+					float sc = 0;
+					for (int a = 0; a < 3; a++) { float cc = 0.5f * (ch[k].b[a] + ch[k].b[3 + a]) - 0.5f * (lo[a] + hi[a]); sc += ((sl >> a) & 1) ? cc : -cc; }
+					cands.push_back({ sc, (int)k, sl });
+				}
+				std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.score > y.score; });
+				std::vector<int> got(ch.size(), -1);
+				for (const Cand& cd : cands) if (got[cd.child] < 0 && !used[cd.slot]) { got[cd.child] = cd.slot; used[cd.slot] = true; }
+				for (size_t k = 0; k < ch.size(); k++) slotOf[k] = got[k];
+			}
+			// emit: inner children get consecutive wide indices in slot order; leaf chunks append their primitives
+			uint8_t metaB[8] = { 0 }, ql[3][8], qh[3][8]; uint32_t imask = 0;
+			for (int sl = 0; sl < 8; sl++) for (int a = 0; a < 3; a++) { ql[a][sl] = 255; qh[a][sl] = 0; }
+			const uint32_t child_base = (uint32_t)(wide.size() / 20);
+			const uint32_t prim_base = (uint32_t)meta.size();
+			int order[8], no = 0; for (int sl = 0; sl < 8; sl++) for (size_t k = 0; k < ch.size(); k++) if (slotOf[k] == sl) order[no++] = (int)k;
+			uint32_t ninner = 0; int poff = 0;
+			for (int oi = 0; oi < no; oi++)
+			{
+				const Child& c = ch[order[oi]]; const int sl = slotOf[order[oi]];
+				if (c.node >= 0) { imask |= 1u << sl; metaB[sl] = (uint8_t)(0x20 | (24 + sl)); queue.push_back({ c.node, child_base + ninner, it.depth + 1 }); ninner++; wide.resize(wide.size() + 20, 0u); }
+				else
+				{
+					// the whole binary leaf is emitted when its first chunk comes up, so that its primitives stay contiguous on the
+					// device and the binary tree (used for closest-hit rays) can address the same records
+					if (devPrimOf[s->bvh_prim_index[c.first]] < 0) for (int k = 0; k < c.leaf_cnt; k++) emit_prim(s->bvh_prim_index[c.leaf_first + k]);
+					poff = devPrimOf[s->bvh_prim_index[c.first]] - (int)prim_base;
+					if (poff < 0 || poff + c.cnt > 24) { ok = false; break; }
+					metaB[sl] = (uint8_t)((((1u << c.cnt) - 1u) << 5) | (unsigned)poff);
+				}
+				for (int a = 0; a < 3; a++)
+				{
+					int q0 = (int)std::floor((c.b[a] - lo[a]) / sc3[a]), q1 = (int)std::ceil((c.b[3 + a] - lo[a]) / sc3[a]);
+					q0 = std::max(0, std::min(255, q0)); q1 = std::max(0, std::min(255, q1));
+					while (q0 > 0 && std::fmaf((float)q0, sc3[a], lo[a]) > c.b[a]) q0--;                     // conservative in fp32, as the device evaluates it
+					while (q1 < 255 && std::fmaf((float)q1, sc3[a], lo[a]) < c.b[3 + a]) q1++;
+					if (std::fmaf((float)q1, sc3[a], lo[a]) < c.b[3 + a]) { ok = false; break; }
+					ql[a][sl] = (uint8_t)q0; qh[a][sl] = (uint8_t)q1;
+				}
+				if (!ok) break;
+			}
+			if (!ok) break;
+			auto pack4 = [](const uint8_t* v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); };
+			uint32_t* w = &wide[(size_t)it.widx * 20];
+			std::memcpy(&w[0], &lo[0], 4); std::memcpy(&w[1], &lo[1], 4); std::memcpy(&w[2], &lo[2], 4);
+			w[3] = (uint32_t)eb[0] | ((uint32_t)eb[1] << 8) | ((uint32_t)eb[2] << 16) | (imask << 24);
+			w[4] = child_base; w[5] = prim_base; w[6] = pack4(metaB); w[7] = pack4(metaB + 4);
+			w[8] = pack4(ql[0]); w[9] = pack4(ql[0] + 4); w[10] = pack4(ql[1]); w[11] = pack4(ql[1] + 4);
+			w[12] = pack4(ql[2]); w[13] = pack4(ql[2] + 4); w[14] = pack4(qh[0]); w[15] = pack4(qh[0] + 4);
+			w[16] = pack4(qh[1]); w[17] = pack4(qh[1] + 4); w[18] = pack4(qh[2]); w[19] = pack4(qh[2] + 4);
+		}
+		if (!ok || (int)meta.size() != s->n_primitives)
+		{   // a foreign BVH with leaves too large for the wide layout: keep the binary tree
+			use_wide = false; wide.clear(); prims.clear(); meta.clear(); std::fill(devPrimOf.begin(), devPrimOf.end(), -1);
+		}
+	}
+
+	// binary device tree (small and medium scenes): interior nodes get device indices in DFS order
+	std::vector<int> order;
+	{ std::vector<int> st; st.push_back(0); while (!st.empty()) { int n = st.back(); st.pop_back(); if (s->bvh_left[n] < 0) continue; hostToDevNode[n] = (int)order.size(); order.push_back(n); st.push_back(s->bvh_right[n]); st.push_back(s->bvh_left[n]); } }
 	const float kEmpty[6] = { 1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f };
 	if (order.empty())
 	{   // the root itself is a leaf: a synthetic interior root whose right child can never be hit
@@ -830,6 +963,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	HIP_TRY(up(&c->d_mats, mats.data(), mats.size() * sizeof(float4)));
 	HIP_TRY(up(&c->d_mat_type, mtype.data(), mtype.size() * sizeof(int)));
 	HIP_TRY(up(&c->d_lights, lights.data(), lights.size() * sizeof(float4)));
+	if (use_wide) HIP_TRY(up(&c->d_wide, wide.data(), wide.size() * sizeof(uint32_t)));
 	if (!flat.empty()) { HIP_TRY(up(&c->d_flat, flat.data(), flat.size() * sizeof(float4))); HIP_TRY(up(&c->d_flat_leaf, flat_leaf.data(), flat_leaf.size() * sizeof(int))); }
 
 	SceneView& v = c->sv;
@@ -840,14 +974,21 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.env_sum = make_float3(envsum[0], envsum[1], envsum[2]); v.n_env = nenv;
 	v.world_radius = s->world_radius; v.cam = s->camera;
 	v.flat = (const float4*)c->d_flat; v.flat_leaf = (const int*)c->d_flat_leaf; v.n_flat = (int)flat_leaf.size();
+	v.wide = (const uint4*)c->d_wide; v.n_wide = (int)(wide.size() / 20);
 	c->stack_depth = std::max(2, height + 2);
 	size_t scene_bytes = (nodes.size() + prims.size()) / 4 * 5 * sizeof(float4);   // 80-byte LDS record stride
 	size_t prim_bytes = prims.size() / 4 * 5 * sizeof(float4);
 	size_t stack_bytes = (size_t)c->stack_depth * JP_BLOCK * sizeof(int);
 	c->scene_in_lds = scene_bytes + stack_bytes <= 40 * 1024;
-	c->trav_mode = (!flat.empty() && prim_bytes <= 40 * 1024) ? 2 : (c->scene_in_lds ? 1 : 0);
-	if (const char* e = getenv("JETPBRT_TRAVERSAL")) { int m = atoi(e); if (m == 0 || (m == 1 && c->scene_in_lds)) c->trav_mode = m; }   // experiments: force a lower mode
+	c->trav_mode = use_wide ? 3 : ((!flat.empty() && prim_bytes <= 40 * 1024) ? 2 : (c->scene_in_lds ? 1 : 0));
+	if (!use_wide) if (const char* e = getenv("JETPBRT_TRAVERSAL")) { int m = atoi(e); if (m == 0 || (m == 1 && c->scene_in_lds)) c->trav_mode = m; }   // experiments: force a lower mode
+	if (use_wide) c->scene_in_lds = false;
+	// large scenes: closest-hit rays walk the binary tree (exact near-to-far order, early out), any-hit shadow rays the
+	// 8-wide quantised tree (fewest node fetches; order irrelevant).  Measured on the 280k-triangle scene:
+	// k_extend 10.3 ms binary vs 13.8 ms wide, k_shadow 10.6 ms binary vs 8.6 ms wide.
+	c->lds_bytes_shadow = c->trav_mode == 3 ? (size_t)2 * (wide_height + 2) * JP_BLOCK * sizeof(int) : 0;
 	c->lds_bytes = c->trav_mode == 2 ? prim_bytes + 128 : (c->trav_mode == 1 ? stack_bytes + scene_bytes : stack_bytes);
+	if (c->trav_mode != 3) c->lds_bytes_shadow = c->lds_bytes;
 	{
 		size_t tab = ((size_t)2 * s->n_lights + (size_t)4 * s->n_materials) * sizeof(float4) + (size_t)s->n_materials * sizeof(int) + 16;
 		c->tables_in_lds = tab <= 16 * 1024;
@@ -978,7 +1119,8 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 				if (it < rp->max_depth || c->has_null_material)                 // at bounce == maxDepth Li() breaks before the NEE (integrator.cc:340-343)
 				{
 					Stamper t(c, CLS_SHADOW);
-					if (c->trav_mode == 2) hipLaunchKernelGGL(k_shadow<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
+					if (c->trav_mode == 3) hipLaunchKernelGGL(k_shadow<3>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes_shadow, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
+					else if (c->trav_mode == 2) hipLaunchKernelGGL(k_shadow<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 					else if (c->trav_mode == 1) hipLaunchKernelGGL(k_shadow<1>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 					else hipLaunchKernelGGL(k_shadow<0>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 				}
@@ -1061,7 +1203,8 @@ int jp_trace(JpContext* c, int32_t n, const float* origin, const float* dir, con
 		hipMemcpyAsync(d_o, origin, (size_t)n * 12, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(d_d, dir, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
 		hipMemcpyAsync(d_t0, tmin, (size_t)n * 4, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(d_t1, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
 		int grid = std::min(c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK);
-		if (c->trav_mode == 2) hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
+		if (c->trav_mode == 3 && getenv("JETPBRT_TRACE_WIDE")) hipLaunchKernelGGL(k_trace<3>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes_shadow, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
+		else if (c->trav_mode == 2) hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		else if (c->trav_mode == 1) hipLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		else hipLaunchKernelGGL(k_trace<0>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		hipMemcpyAsync(hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream); hipMemcpyAsync(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);

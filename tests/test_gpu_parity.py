@@ -321,3 +321,28 @@ def test_large_film_and_deep_paths(H, gpu_ctx):
         y0, y1 = b * 20, min(Hh, b * 20 + 20)
         d = np.sqrt(((film[y0:y1] - ref[y0:y1]) ** 2).sum(-1)); tot += d.sum(); npx += d.size
     assert tot / npx < 2e-4, tot / npx                     # 1 spp: a single flipped path moves a pixel by O(1); still tiny on average
+
+
+def test_wide_bvh_closest_hit_records(H, gpu_ctx, tmp_path, monkeypatch):
+    """large-scene mode: shadow rays walk the 8-wide quantised tree; its closest-hit variant (test hook) must return the
+    very same hit records as the oracle's reference-style binary tree"""
+    hb = H.build_random_scene(H.scenes.HostBackend("r"), 32, 32, 11, n_tris=2000, tmpdir=str(tmp_path))
+    sp = hb.flatten()
+    gpu_ctx.upload(sp)
+    rng = np.random.default_rng(2)
+    m = 100000
+    o = rng.uniform(-4, 4, (m, 3)).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:1000, 2] = 0.0
+    tmin = np.full(m, 0.001, np.float32); tmax = np.where(rng.random(m) < 0.5, np.inf, rng.random(m) * 6).astype(np.float32)
+    L = H.oracle_lib(); oh = L.jp_oracle_scene_new(sp)
+    ohit = np.zeros(m, np.int32); ot = np.zeros(m, np.float32); oprim = np.zeros(m, np.int32); onrm = np.zeros((m, 3), np.float32); opos = np.zeros((m, 3), np.float32)
+    L.jp_oracle_trace(oh, m, H.ptr(o), H.ptr(d), H.ptr(tmin), H.ptr(tmax), H.ptr(ohit), H.ptr(ot), H.ptr(oprim), H.ptr(onrm), H.ptr(opos))
+    L.jp_oracle_scene_free(oh)
+    for wide in (False, True):
+        if wide:
+            monkeypatch.setenv("JETPBRT_TRACE_WIDE", "1")
+        hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
+        assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)) and (prim == oprim).mean() > 0.9999, wide
+    monkeypatch.delenv("JETPBRT_TRACE_WIDE")
+    assert ohit.mean() > 0.3
