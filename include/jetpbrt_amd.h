@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define JP_ABI_VERSION 1
+#define JP_ABI_VERSION 2
 
 typedef enum JpStatus {
     JP_OK = 0,
@@ -36,8 +36,9 @@ enum { JP_SHAPE_TRIANGLE = 0, JP_SHAPE_RECTANGLE = 1, JP_SHAPE_SPHERE = 2 };
 /* material kinds: material.h:27-41 (matte), :45-59 (mirror), :63-81 (glass), :85-110 + material.cc:12-29
  * (plastic), material.h:113-137 + material.cc:31-43 (metal) */
 enum { JP_MAT_MATTE = 0, JP_MAT_MIRROR = 1, JP_MAT_GLASS = 2, JP_MAT_PLASTIC = 3, JP_MAT_METAL = 4 };
-/* light kinds: FEnvironmentLight light.h:248-311, FAreaLight light.h:183-244 */
-enum { JP_LIGHT_ENVIRONMENT = 0, JP_LIGHT_AREA = 1 };
+/* light kinds: FEnvironmentLight light.h:248-311, FAreaLight light.h:183-244, FPointLight light.h:81-132,
+ * FDirectionLight light.h:136-180 */
+enum { JP_LIGHT_ENVIRONMENT = 0, JP_LIGHT_AREA = 1, JP_LIGHT_POINT = 2, JP_LIGHT_DIRECTION = 3 };
 /* sampler: the stock sequential mt19937_64 stream (sampler.h:16-54) cannot be reproduced by a parallel
  * device; the device path implements the counter-based stream of include/jp_counter_rng.h only. */
 enum { JP_SAMPLER_STOCK_MT19937 = 0, JP_SAMPLER_COUNTER = 1 };
@@ -77,9 +78,11 @@ typedef struct JpScene {
     /* lights in FScene::Lights() order (creation order; scene.h:92-106) */
     int32_t n_lights;
     const int32_t *light_type;         /* JP_LIGHT_*                                    */
-    const float   *light_radiance;     /* rgb                                            */
-    const int32_t *light_prim;         /* AREA: primitive whose shape emits; ENVIRONMENT: -1 */
-    float world_radius;                /* FEnvironmentLight::worldRadius after Preprocess (light.cc:26-33) */
+    const float   *light_radiance;     /* rgb: radiance (AREA, ENVIRONMENT), intensity (POINT), irradiance (DIRECTION) */
+    const int32_t *light_prim;         /* AREA: primitive whose shape emits; otherwise -1 */
+    const float   *light_vec;          /* xyz per light: POINT worldPosition, DIRECTION normalised worldDir, otherwise 0;
+                                          may be NULL when the scene has neither kind */
+    float world_radius;                /* FEnvironmentLight / FDirectionLight::worldRadius after Preprocess (light.cc:17-33) */
 
     /* bounding volume hierarchy over the primitives, built by the host (own topology; closest-hit and
      * occlusion results do not depend on it).  Node i: bounds 6 floats (min xyz, max xyz);

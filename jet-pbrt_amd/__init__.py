@@ -37,7 +37,7 @@ class JpScene(C.Structure):
         ("n_spheres", C.c_int32), ("sph_center", _fp), ("sph_radius", _fp),
         ("n_primitives", C.c_int32), ("prim_shape_type", _ip), ("prim_shape_index", _ip), ("prim_material", _ip), ("prim_light", _ip),
         ("n_materials", C.c_int32), ("mat_type", _ip), ("mat_params", _fp),
-        ("n_lights", C.c_int32), ("light_type", _ip), ("light_radiance", _fp), ("light_prim", _ip),
+        ("n_lights", C.c_int32), ("light_type", _ip), ("light_radiance", _fp), ("light_prim", _ip), ("light_vec", _fp),
         ("world_radius", C.c_float),
         ("n_bvh_nodes", C.c_int32), ("bvh_bounds", _fp), ("bvh_left", _ip), ("bvh_right", _ip),
         ("n_bvh_prim_indices", C.c_int32), ("bvh_prim_index", _ip),
@@ -85,6 +85,8 @@ def host_lib():
         L.jp_host_last_error.argtypes = [C.c_void_p]
         L.jp_host_scene_camera.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float]
         L.jp_host_scene_envlight.argtypes = [C.c_void_p, _fp]
+        L.jp_host_scene_pointlight.argtypes = [C.c_void_p, _fp, _fp]
+        L.jp_host_scene_dirlight.argtypes = [C.c_void_p, _fp, _fp]
         L.jp_host_mat_matte.argtypes = [C.c_void_p, _fp]
         L.jp_host_mat_mirror.argtypes = [C.c_void_p, _fp]
         L.jp_host_mat_glass.argtypes = [C.c_void_p, C.c_float, _fp, _fp]

@@ -59,7 +59,7 @@ struct SceneView
 	const float4* prims; const int4* meta; int n_prims;
 	const float4* mats;                     // 4 x float4 per material (JP_MAT_PARAM_STRIDE floats)
 	const int* mat_type; int n_mats;
-	const float4* lights;                   // 2 x float4 per light: (radiance, type bits), (device prim bits, inv_area, -, -)
+	const float4* lights;                   // 2 x float4 per light: (radiance, type bits), then AREA (device prim bits, 1/area, -, -), POINT / DIRECTION (vec xyz, -)
 	int n_lights;
 	float3 env_sum;                         // sum of the infinite lights' radiance in Lights() order (light.h:300-303)
 	int n_env;

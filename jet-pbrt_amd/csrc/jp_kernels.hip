@@ -696,6 +696,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	for (int i = 0; i < s->n_lights; i++)
 	{
 		if (s->light_type[i] == JP_LIGHT_AREA) { if (s->light_prim[i] < 0 || s->light_prim[i] >= s->n_primitives) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: area light primitive out of range"); }
+		else if (s->light_type[i] == JP_LIGHT_POINT || s->light_type[i] == JP_LIGHT_DIRECTION) { if (!s->light_vec) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: point / direction light without light_vec"); }
 		else if (s->light_type[i] != JP_LIGHT_ENVIRONMENT) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: unknown light type");
 	}
 	// BVH: a tree, every primitive in exactly one leaf, leaf ranges in bounds, height within the LDS stack
@@ -947,9 +948,10 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 			else { const float kPi = (float)3.14159265358979323846; float r2 = s->sph_radius[k] * s->sph_radius[k]; area = 4 * kPi * r2; }
 			inv_area = 1 / area;
 		}
-		else { nenv++; envsum[0] += rad[0]; envsum[1] += rad[1]; envsum[2] += rad[2]; }
+		else if (ty == JP_LIGHT_ENVIRONMENT) { nenv++; envsum[0] += rad[0]; envsum[1] += rad[1]; envsum[2] += rad[2]; }
 		float df; std::memcpy(&df, &dp, 4);
 		lights[2 * i + 1] = make_float4(df, inv_area, 0, 0);
+		if (ty == JP_LIGHT_POINT || ty == JP_LIGHT_DIRECTION) lights[2 * i + 1] = make_float4(s->light_vec[3 * i], s->light_vec[3 * i + 1], s->light_vec[3 * i + 2], 0);
 	}
 	// meta.z must index lights (already does); fix nothing else.
 

@@ -350,6 +350,23 @@ __device__ __forceinline__ LightSample sample_li(const SceneView& sc, PrimPtr pr
 		s.Li = radiance;
 		return s;
 	}
+	if (__float_as_int(l0.w) == JP_LIGHT_POINT)                   // FPointLight::Sample_Li light.h:94-123; l1.xyz = worldPosition
+	{
+		const V3 wp = xyz(l1);
+		s.pos = wp;
+		s.wi = normalize(wp - p);
+		s.pdf = 1.f;
+		s.Li = radiance / len2(wp - p);
+		return s;
+	}
+	if (__float_as_int(l0.w) == JP_LIGHT_DIRECTION)               // FDirectionLight::Sample_Li light.h:155-164; l1.xyz = worldDir
+	{
+		s.wi = -xyz(l1);
+		s.pos = p + s.wi * 2 * sc.world_radius;
+		s.pdf = 1.f;
+		s.Li = radiance;
+		return s;
+	}
 	const int pi = __float_as_int(l1.x);
 	const float inv_area = l1.y;                                  // 1 / FShape::Area(), precomputed at upload with the reference's expression
 	const float4 g0 = prims[4 * pi + 0], g3 = prims[4 * pi + 3];

@@ -39,6 +39,11 @@ void jp_host_scene_camera(void* h, const float* lookfrom, const float* front, co
 int jp_host_scene_envlight(void* h, const float* rgb)
 { HostScene* hs = (HostScene*)h; hs->scene->CreateLight<FEnvironmentLight>(FPoint3(0, 0, 0), 1, C3(rgb)); return hs->scene->LightNum() - 1; }
 
+int jp_host_scene_pointlight(void* h, const float* pos, const float* intensity)
+{ HostScene* hs = (HostScene*)h; hs->scene->CreateLight<FPointLight>(V3(pos), 1, C3(intensity)); return hs->scene->LightNum() - 1; }
+int jp_host_scene_dirlight(void* h, const float* dir, const float* irradiance)
+{ HostScene* hs = (HostScene*)h; hs->scene->CreateLight<FDirectionLight>(FPoint3(0, 0, 0), 1, C3(irradiance), V3(dir)); return hs->scene->LightNum() - 1; }
+
 int jp_host_mat_matte(void* h, const float* rgb) { HostScene* hs = (HostScene*)h; hs->mats.push_back(hs->scene->CreateMaterial<FMatteMaterial>(C3(rgb))); return (int)hs->mats.size() - 1; }
 int jp_host_mat_mirror(void* h, const float* rgb) { HostScene* hs = (HostScene*)h; hs->mats.push_back(hs->scene->CreateMaterial<FMirrorMaterial>(C3(rgb))); return (int)hs->mats.size() - 1; }
 int jp_host_mat_glass(void* h, float eta, const float* kr, const float* kt) { HostScene* hs = (HostScene*)h; hs->mats.push_back(hs->scene->CreateMaterial<FGlassMaterial>(eta, C3(kr), C3(kt))); return (int)hs->mats.size() - 1; }

@@ -158,6 +158,13 @@ class FEnvironmentLight : public FLight                          // light.h:248-
 { public: FEnvironmentLight(const FPoint3&, int, const FColor& radiance) : FLight(eLightFlags::InfiniteLight), radiance(radiance), worldRadius(0) {}
   int Kind() const override { return JP_LIGHT_ENVIRONMENT; } void Preprocess(const FScene& scene) override; FColor radiance; FPoint3 worldCenter; Float worldRadius; };
 
+class FPointLight : public FLight                                // light.h:81-132
+{ public: FPointLight(const FPoint3& worldpos, int, const FColor& intensity) : FLight(eLightFlags::DeltaPosition), worldPosition(worldpos), intensity(intensity) {}
+  int Kind() const override { return JP_LIGHT_POINT; } FPoint3 worldPosition; FColor intensity; };
+class FDirectionLight : public FLight                            // light.h:136-180, light.cc:17-24
+{ public: FDirectionLight(const FPoint3&, int, const FColor& irradiance, const FVector3& worlddir) : FLight(eLightFlags::DeltaDirection), irradiance(irradiance), worldDir(Normalize(worlddir)), worldRadius(0) {}
+  int Kind() const override { return JP_LIGHT_DIRECTION; } void Preprocess(const FScene& scene) override; FColor irradiance; FVector3 worldDir; FPoint3 worldCenter; Float worldRadius; };
+
 struct FPrimitive                                                // primitive.h:20-64
 {
 	const FShape* shape; const FMaterial* material; const FAreaLight* arealight;
@@ -259,7 +266,7 @@ struct FlatScene
 	JpScene view;
 	std::vector<float> tri_p0, tri_p1, tri_p2, tri_n, rect_p0, rect_p1, rect_p2, rect_p3, rect_n, sph_center, sph_radius;
 	std::vector<int32_t> prim_shape_type, prim_shape_index, prim_material, prim_light, mat_type, light_type, light_prim;
-	std::vector<float> mat_params, light_radiance;
+	std::vector<float> mat_params, light_radiance, light_vec;
 	FlatBVH bvh;
 };
 bool FlattenScene(const FScene& scene, FlatScene& out, std::string* error = nullptr);

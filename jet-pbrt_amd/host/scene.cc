@@ -168,6 +168,12 @@ void FEnvironmentLight::Preprocess(const FScene& scene)                  // ligh
 	bound.BoundingSphere(worldCenter, worldRadius);
 }
 
+void FDirectionLight::Preprocess(const FScene& scene)                    // light.cc:17-24
+{
+	FBounds3 bound = scene.WorldBound();
+	bound.BoundingSphere(worldCenter, worldRadius);
+}
+
 // ---- scene (scene.cc) -------------------------------------------------------------------------------------------
 std::vector<std::shared_ptr<FShape>> FScene::CreateTriangleMesh(const char* filename, bool flip_normal, bool bFlipHandedness, const FVector3& offset, Float inScale)
 {
@@ -259,21 +265,21 @@ bool FlattenScene(const FScene& scene, FlatScene& out, std::string* error)
 	{
 		const FLight* L = scene.lights[i].get();
 		out.light_type.push_back(L->Kind());
+		FColor rad; FVector3 vec(0, 0, 0); int prim = -1;
 		if (L->Kind() == JP_LIGHT_AREA)
 		{
 			const FAreaLight* a = static_cast<const FAreaLight*>(L);
-			out.light_radiance.push_back(a->radiance.r); out.light_radiance.push_back(a->radiance.g); out.light_radiance.push_back(a->radiance.b);
+			rad = a->radiance;
 			auto sp = shapePrim.find(a->shape);
 			if (sp == shapePrim.end()) return fail("FlattenScene: area light whose shape has no primitive");
-			out.light_prim.push_back(sp->second);
+			prim = sp->second;
 		}
-		else
-		{
-			const FEnvironmentLight* e = static_cast<const FEnvironmentLight*>(L);
-			out.light_radiance.push_back(e->radiance.r); out.light_radiance.push_back(e->radiance.g); out.light_radiance.push_back(e->radiance.b);
-			out.light_prim.push_back(-1);
-			worldRadius = e->worldRadius;
-		}
+		else if (L->Kind() == JP_LIGHT_POINT) { const FPointLight* q = static_cast<const FPointLight*>(L); rad = q->intensity; vec = q->worldPosition; }
+		else if (L->Kind() == JP_LIGHT_DIRECTION) { const FDirectionLight* q = static_cast<const FDirectionLight*>(L); rad = q->irradiance; vec = q->worldDir; worldRadius = q->worldRadius; }
+		else { const FEnvironmentLight* e = static_cast<const FEnvironmentLight*>(L); rad = e->radiance; worldRadius = e->worldRadius; }
+		out.light_radiance.push_back(rad.r); out.light_radiance.push_back(rad.g); out.light_radiance.push_back(rad.b);
+		out.light_vec.push_back(vec.x); out.light_vec.push_back(vec.y); out.light_vec.push_back(vec.z);
+		out.light_prim.push_back(prim);
 	}
 	out.bvh = scene.bvh;
 
@@ -289,7 +295,7 @@ bool FlattenScene(const FScene& scene, FlatScene& out, std::string* error)
 	v.n_primitives = (int)out.prim_shape_type.size(); v.prim_shape_type = out.prim_shape_type.data(); v.prim_shape_index = out.prim_shape_index.data();
 	v.prim_material = out.prim_material.data(); v.prim_light = out.prim_light.data();
 	v.n_materials = (int)out.mat_type.size(); v.mat_type = out.mat_type.data(); v.mat_params = out.mat_params.data();
-	v.n_lights = (int)out.light_type.size(); v.light_type = out.light_type.data(); v.light_radiance = out.light_radiance.data(); v.light_prim = out.light_prim.data();
+	v.n_lights = (int)out.light_type.size(); v.light_type = out.light_type.data(); v.light_radiance = out.light_radiance.data(); v.light_prim = out.light_prim.data(); v.light_vec = out.light_vec.data();
 	v.world_radius = worldRadius;
 	v.n_bvh_nodes = (int)out.bvh.left.size(); v.bvh_bounds = out.bvh.bounds.data(); v.bvh_left = out.bvh.left.data(); v.bvh_right = out.bvh.right.data();
 	v.n_bvh_prim_indices = (int)out.bvh.prim_index.size(); v.bvh_prim_index = out.bvh.prim_index.data();

@@ -188,6 +188,12 @@ class HostBackend:
     def envlight(self, rgb):
         a, _a = _fa(rgb); return self._f("scene_envlight")(self.h, a)
 
+    def pointlight(self, pos, intensity):
+        a, _a = _fa(pos); b, _b = _fa(intensity); return self._f("scene_pointlight")(self.h, a, b)
+
+    def dirlight(self, direction, irradiance):
+        a, _a = _fa(direction); b, _b = _fa(irradiance); return self._f("scene_dirlight")(self.h, a, b)
+
     def mat_matte(self, rgb):
         a, _a = _fa(rgb); return self._f("mat_matte")(self.h, a)
 
@@ -311,6 +317,15 @@ def build_misc(be, width, height):
         b.rect(AXIS_XY, 150, 400, 100, 400, 500, False, -1, None)          # null material: rays pass through
     be_ = build_cornell(be, width, height, lambert_only=False, extras=extras, env=(0.05, 0.08, 0.2))
     return be_
+
+
+def build_lights(be, width, height):
+    """Cornell box lit additionally by the delta lights of light.h:81-180 (FPointLight, FDirectionLight -- only in
+    commented-out lines of main.cc:38,82) and a dim environment."""
+    def extras(b, m):
+        b.pointlight((278, 273, -200), (630000.0 * 0.2, 650000.0 * 0.2, 650000.0 * 0.2))
+        b.dirlight((0.3, -1.0, -0.6), (1.5, 1.2, 0.9))
+    return build_cornell(be, width, height, lambert_only=False, extras=extras, env=(0.02, 0.02, 0.05))
 
 
 def export_reference_layout(root, n_lon=187, n_lat=188):

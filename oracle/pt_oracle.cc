@@ -756,6 +756,23 @@ inline LightSample sample_li(const Scene& sc, int li, const Isect& is, float ux,
 		s.Li = radiance;
 		return s;
 	}
+	if (js->light_type[li] == JP_LIGHT_POINT)                                 // FPointLight::Sample_Li light.h:94-123
+	{
+		V3 wp = ld3(js->light_vec + 3 * li);
+		s.pos = wp;
+		s.wi = normalize(wp - is.p);
+		s.pdf = 1.f;
+		s.Li = radiance / len2(wp - is.p);
+		return s;
+	}
+	if (js->light_type[li] == JP_LIGHT_DIRECTION)                             // FDirectionLight::Sample_Li light.h:155-164
+	{
+		s.wi = -ld3(js->light_vec + 3 * li);
+		s.pos = is.p + s.wi * 2 * js->world_radius;
+		s.pdf = 1.f;
+		s.Li = radiance;
+		return s;
+	}
 	V3 lp, ln;                                                                // FAreaLight::Sample_Li light.h:199-216
 	sample_direction(sc, js->light_prim[li], is, ux, uy, lp, ln, s.pdf);
 	s.pos = lp;

@@ -145,6 +145,11 @@ int ref_scene_envlight(void* h, const float* rgb)
 	return rs->scene->LightNum() - 1;
 }
 
+int ref_scene_pointlight(void* h, const float* pos, const float* intensity)
+{ RefScene* rs = (RefScene*)h; rs->scene->CreateLight<FPointLight>(V3(pos), 1, C3(intensity)); return rs->scene->LightNum() - 1; }   // main.cc:38 (commented-out line)
+int ref_scene_dirlight(void* h, const float* dir, const float* irradiance)
+{ RefScene* rs = (RefScene*)h; rs->scene->CreateLight<FDirectionLight>(FPoint3(0, 0, 0), 1, C3(irradiance), V3(dir)); return rs->scene->LightNum() - 1; }
+
 int ref_mat_matte(void* h, const float* rgb)
 { RefScene* rs = (RefScene*)h; rs->mats.push_back(rs->scene->CreateMaterial<FMatteMaterial>(C3(rgb))); return (int)rs->mats.size() - 1; }
 int ref_mat_mirror(void* h, const float* rgb)

@@ -58,6 +58,8 @@ def ref_lib():
         L.ref_scene_free.argtypes = [_vp]
         L.ref_scene_camera.argtypes = [_vp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float]
         L.ref_scene_envlight.argtypes = [_vp, _fp]
+        L.ref_scene_pointlight.argtypes = [_vp, _fp, _fp]
+        L.ref_scene_dirlight.argtypes = [_vp, _fp, _fp]
         L.ref_mat_matte.argtypes = [_vp, _fp]
         L.ref_mat_mirror.argtypes = [_vp, _fp]
         L.ref_mat_glass.argtypes = [_vp, C.c_float, _fp, _fp]
@@ -119,6 +121,7 @@ SCENES = {
     # the committed OBJ fixture (numpy's sin/cos may differ in the last bit between hosts; the goldens must not)
     "bunny_small": lambda be, W, H: scenes.build_bunny(be, W, H, obj_path=os.path.join(GOLDEN, "bunny_24x16.obj")),
     "misc": lambda be, W, H: scenes.build_misc(be, W, H),
+    "lights": lambda be, W, H: scenes.build_lights(be, W, H),
 }
 
 

@@ -15,7 +15,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 TOL_L2 = 1e-4
-SCENE_NAMES = ["cornell", "cornell_lambert", "bunny_small", "misc"]
+SCENE_NAMES = ["cornell", "cornell_lambert", "bunny_small", "misc", "lights"]
 
 
 def l2(a, b):

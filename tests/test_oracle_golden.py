@@ -9,7 +9,7 @@ import pytest
 
 W = Hh = 48
 SPP = 8
-SCENE_NAMES = ["cornell", "cornell_lambert", "bunny_small", "misc"]
+SCENE_NAMES = ["cornell", "cornell_lambert", "bunny_small", "misc", "lights"]
 
 
 def _scene(H, name):

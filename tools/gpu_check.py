@@ -13,7 +13,7 @@ def l2(a, b):
 def main():
     ctx = jp.Context(0)
     rng = np.random.default_rng(1)
-    for name in ["cornell_lambert", "cornell", "bunny_small", "misc"]:
+    for name in ["cornell_lambert", "cornell", "bunny_small", "misc", "lights"]:
         W, Hh, spp = 96, 96, 16
         hb = H.SCENES[name](H.scenes.HostBackend(name), W, Hh)
         sp = hb.flatten()
