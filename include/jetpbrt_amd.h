@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define JP_ABI_VERSION 2
+#define JP_ABI_VERSION 3
 
 typedef enum JpStatus {
     JP_OK = 0,
@@ -88,7 +88,9 @@ typedef struct JpScene {
      * occlusion results do not depend on it).  Node i: bounds 6 floats (min xyz, max xyz);
      * bvh_left[i] >= 0: interior, children bvh_left[i], bvh_right[i];
      * bvh_left[i] <  0: leaf, primitives bvh_prim_index[first .. first+count) with first = -bvh_left[i]-1,
-     *                   count = bvh_right[i].  Node 0 is the root. */
+     *                   count = bvh_right[i].  Node 0 is the root.
+     * n_bvh_nodes == 0 (all four pointers may be NULL): no hierarchy is handed over and jp_upload_scene builds one on
+     * the device from the primitive extents (LBVH; replaces the host build of FScene::Preprocess, scene.cc:11-23). */
     int32_t n_bvh_nodes;   const float *bvh_bounds; const int32_t *bvh_left, *bvh_right;
     int32_t n_bvh_prim_indices; const int32_t *bvh_prim_index;
 } JpScene;
@@ -118,6 +120,14 @@ typedef struct JpCounters {
     uint64_t extend_launches, shade_launches, shadow_launches;
 } JpCounters;
 
+/* what jp_upload_scene did with the hierarchy */
+typedef struct JpBuildInfo {
+    int32_t built_on_device;     /* 1: built by the device LBVH pass, 0: the caller's tree was used          */
+    int32_t traversal_mode;      /* 0 binary tree in HBM, 1 binary tree in LDS, 2 flat leaf list, 3 binary + 8-wide */
+    int32_t bvh_nodes, bvh_height;
+    double  device_build_ms;     /* HIP-event time of the device build (0 when the caller's tree was used)     */
+} JpBuildInfo;
+
 typedef struct JpContext JpContext;
 
 const char* jp_last_error(void);
@@ -142,6 +152,7 @@ int  jp_synchronize(JpContext* ctx);
 /* per-kernel-class event timing (adds two events per launch); off by default */
 int  jp_set_profiling(JpContext* ctx, int enabled);
 int  jp_get_counters(JpContext* ctx, JpCounters* out);
+int  jp_get_build_info(JpContext* ctx, JpBuildInfo* out);
 
 /* test hook: closest-hit query for n rays (FScene::Intersect, scene.cc:25-33).  Host arrays:
  * origin/dir 3n floats, tmin/tmax n floats -> hit (0/1), t (ray.max_t after the call), prim (-1 if none),

@@ -58,6 +58,11 @@ class JpCounters(C.Structure):
                 ("extend_launches", C.c_uint64), ("shade_launches", C.c_uint64), ("shadow_launches", C.c_uint64)]
 
 
+class JpBuildInfo(C.Structure):
+    _fields_ = [("built_on_device", C.c_int32), ("traversal_mode", C.c_int32), ("bvh_nodes", C.c_int32), ("bvh_height", C.c_int32),
+                ("device_build_ms", C.c_double)]
+
+
 def render_params(width, height, spp, max_depth=5, seed=1234, sampler_mode=JP_SAMPLER_COUNTER,
                   band_rows=20, shard_index=0, shard_count=1):
     return JpRenderParams(width, height, spp, max_depth, sampler_mode, seed, band_rows, shard_index, shard_count, 0)
@@ -96,6 +101,7 @@ def host_lib():
         L.jp_host_scene_rect.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _fp]
         L.jp_host_scene_sphere.argtypes = [C.c_void_p, _fp, C.c_float, C.c_int, _fp]
         L.jp_host_scene_preprocess.argtypes = [C.c_void_p]
+        L.jp_host_scene_set_device_build.argtypes = [C.c_void_p, C.c_int]
         L.jp_host_num_primitives.argtypes = [C.c_void_p]
         L.jp_host_num_lights.argtypes = [C.c_void_p]
         L.jp_host_flatten.restype = C.POINTER(JpScene)
@@ -123,6 +129,7 @@ def hip_lib():
         L.jp_synchronize.argtypes = [C.c_void_p]
         L.jp_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.jp_get_counters.argtypes = [C.c_void_p, C.POINTER(JpCounters)]
+        L.jp_get_build_info.argtypes = [C.c_void_p, C.POINTER(JpBuildInfo)]
         L.jp_trace.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 8
         _hip = L
     return _hip
@@ -162,6 +169,11 @@ class Context:
         c = JpCounters()
         self._check(self.lib.jp_get_counters(self.h, C.byref(c)))
         return c
+
+    def build_info(self):
+        b = JpBuildInfo()
+        self._check(self.lib.jp_get_build_info(self.h, C.byref(b)))
+        return b
 
     def trace(self, origin, direction, tmin, tmax):
         import numpy as np

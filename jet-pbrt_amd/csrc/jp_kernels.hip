@@ -22,6 +22,7 @@
 #include <vector>
 #include <algorithm>
 #include <cmath>
+#include "jp_lbvh.h"
 
 using namespace jp;
 
@@ -574,6 +575,7 @@ struct JpContext
 	void *d_flat = nullptr, *d_flat_leaf = nullptr, *d_wide = nullptr; int trav_mode = 0;
 	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr;
 	int n_planes = 1; bool has_null_material = false;
+	bool build_on_device = false; float build_ms = 0.f; int bvh_height = 0, bvh_nodes = 0;
 	bool tables_in_lds = false, stage_nee = false; size_t shade_lds_bytes = 0;
 	// queues
 	Queues q; unsigned int cap = 0; int planes_alloc = 0; unsigned int blk_alloc = 0; int blocks_per_cu = 16;
@@ -673,9 +675,10 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	if (!c || !s) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: null argument");
 	// ---- validate every index on the host: a bad index must never reach a kernel ----
 	if (s->n_primitives <= 0) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: scene has no primitives");
-	if (s->n_triangles < 0 || s->n_rectangles < 0 || s->n_spheres < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_bvh_nodes <= 0 || s->n_bvh_prim_indices < 0)
+	if (s->n_triangles < 0 || s->n_rectangles < 0 || s->n_spheres < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_bvh_nodes < 0 || s->n_bvh_prim_indices < 0)
 		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: negative count");
-	if (!s->prim_shape_type || !s->prim_shape_index || !s->prim_material || !s->prim_light || !s->bvh_bounds || !s->bvh_left || !s->bvh_right || !s->bvh_prim_index)
+	const bool device_build = s->n_bvh_nodes == 0;              // no hierarchy handed over: build it on the device (jp_lbvh.h)
+	if (!s->prim_shape_type || !s->prim_shape_index || !s->prim_material || !s->prim_light || (!device_build && (!s->bvh_bounds || !s->bvh_left || !s->bvh_right || !s->bvh_prim_index)))
 		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: null array");
 	if ((s->n_triangles && (!s->tri_p0 || !s->tri_p1 || !s->tri_p2 || !s->tri_n)) || (s->n_rectangles && (!s->rect_p0 || !s->rect_p1 || !s->rect_p2 || !s->rect_p3 || !s->rect_n))
 	    || (s->n_spheres && (!s->sph_center || !s->sph_radius)) || (s->n_materials && (!s->mat_type || !s->mat_params)) || (s->n_lights && (!s->light_type || !s->light_radiance || !s->light_prim)))
@@ -701,9 +704,9 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	}
 	// BVH: a tree, every primitive in exactly one leaf, leaf ranges in bounds, height within the LDS stack
 	std::vector<char> seen(s->n_bvh_nodes, 0); bool bad = false;
-	int height = bvh_height(s, 0, 0, 4 * JP_STACK_DEPTH, bad, seen);
+	int height = device_build ? 0 : bvh_height(s, 0, 0, 4 * JP_STACK_DEPTH, bad, seen);
 	if (bad) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: BVH is not a tree rooted at node 0 (cycle, bad child index or excessive depth)");
-	if (height + 1 > JP_STACK_DEPTH) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: BVH height exceeds the device traversal stack (32)");
+	if (!device_build && height + 1 > JP_STACK_DEPTH) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: BVH height exceeds the device traversal stack (32)");
 	std::vector<int> primSeen(s->n_primitives, 0);
 	for (int n = 0; n < s->n_bvh_nodes; n++)
 	{
@@ -713,7 +716,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		if (cnt < 1 || cnt > 16 || first < 0 || first + cnt > s->n_bvh_prim_indices) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: BVH leaf range invalid (1..16 primitives per leaf)");
 		for (int k = 0; k < cnt; k++) { int p = s->bvh_prim_index[first + k]; if (p < 0 || p >= s->n_primitives) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: BVH primitive index out of range"); primSeen[p]++; }
 	}
-	for (int i = 0; i < s->n_primitives; i++) if (primSeen[i] != 1) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: every primitive must be in exactly one BVH leaf");
+	if (!device_build) for (int i = 0; i < s->n_primitives; i++) if (primSeen[i] != 1) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: every primitive must be in exactly one BVH leaf");
 
 	HIP_TRY(hipSetDevice(c->device));
 	HIP_TRY(hipStreamSynchronize(c->stream));
@@ -762,7 +765,8 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	// ---- large scenes: collapse the binary tree into 8-wide nodes with quantised child boxes (traverse_wide) ----
 	int nleaves_total = 0; for (int n = 0; n < s->n_bvh_nodes; n++) if (seen[n] && s->bvh_left[n] < 0) nleaves_total++;
 	std::vector<uint32_t> wide; int wide_height = 0;
-	bool use_wide = nleaves_total > 32 && s->bvh_left[0] >= 0;
+	bool use_wide = !device_build && nleaves_total > 32 && s->bvh_left[0] >= 0;
+	if (!device_build)
 	{
 		size_t est = ((size_t)s->n_bvh_nodes + (size_t)s->n_primitives) * 80;                            // LDS-resident scenes keep the binary tree
 		if (est + (size_t)(height + 2) * JP_BLOCK * sizeof(int) <= 40 * 1024) use_wide = false;
@@ -882,9 +886,10 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 
 	// binary device tree (small and medium scenes): interior nodes get device indices in DFS order
 	std::vector<int> order;
-	{ std::vector<int> st; st.push_back(0); while (!st.empty()) { int n = st.back(); st.pop_back(); if (s->bvh_left[n] < 0) continue; hostToDevNode[n] = (int)order.size(); order.push_back(n); st.push_back(s->bvh_right[n]); st.push_back(s->bvh_left[n]); } }
+	if (!device_build) { std::vector<int> st; st.push_back(0); while (!st.empty()) { int n = st.back(); st.pop_back(); if (s->bvh_left[n] < 0) continue; hostToDevNode[n] = (int)order.size(); order.push_back(n); st.push_back(s->bvh_right[n]); st.push_back(s->bvh_left[n]); } }
 	const float kEmpty[6] = { 1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f };
-	if (order.empty())
+	if (device_build) {}
+	else if (order.empty())
 	{   // the root itself is a leaf: a synthetic interior root whose right child can never be hit
 		float lb[6]; pad_box(0, lb);
 		int ref = emit_leaf(0), rr = ref; float fr, fl; std::memcpy(&fl, &ref, 4); std::memcpy(&fr, &rr, 4);
@@ -905,10 +910,38 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 			nodes[4 * di + 2] = make_float4(rb[2], rb[3], rb[4], rb[5]); nodes[4 * di + 3] = make_float4(fl, fr, 0, 0);
 		}
 	}
-	if (meta.size() >= (1u << 27)) return fail(JP_ERR_UNSUPPORTED, "jp_upload_scene: too many primitives for the leaf reference encoding");
+	if ((size_t)s->n_primitives >= (1u << 27)) return fail(JP_ERR_UNSUPPORTED, "jp_upload_scene: too many primitives for the leaf reference encoding");
+
+	// ---- no hierarchy handed over: records go up in creation order and the tree is built on the device (jp_lbvh.h) ----
+	size_t n4nodes = nodes.size(), n4prims = prims.size(), nmeta = meta.size();
+	c->build_on_device = device_build; c->build_ms = 0.f;
+	if (device_build)
+	{
+		for (int p = 0; p < s->n_primitives; p++) emit_prim(p);
+		void *d_p0 = nullptr, *d_m0 = nullptr;
+		hipError_t e = hipMalloc(&d_p0, prims.size() * sizeof(float4)); if (e == hipSuccess) e = hipMalloc(&d_m0, meta.size() * sizeof(int4));
+		if (e == hipSuccess) e = hipMemcpyAsync(d_p0, prims.data(), prims.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream);
+		if (e == hipSuccess) e = hipMemcpyAsync(d_m0, meta.data(), meta.size() * sizeof(int4), hipMemcpyHostToDevice, c->stream);
+		LbvhResult lr; std::vector<int> sorted;
+		int maxLeaf = 4; if (const char* ev = getenv("JETPBRT_BVH_MAXLEAF")) { int v = atoi(ev); if (v >= 1 && v <= 16) maxLeaf = v; }
+		if (e == hipSuccess) e = lbvh_build(c->stream, (const float4*)d_p0, (const int4*)d_m0, s->n_primitives, maxLeaf, lr, sorted);
+		if (d_p0) hipFree(d_p0); if (d_m0) hipFree(d_m0);
+		if (e != hipSuccess) return fail(JP_ERR_DEVICE, std::string("jp_upload_scene: device BVH build failed: ") + hipGetErrorString(e));
+		if (lr.height + 2 > 60)
+		{
+			hipFree(lr.d_nodes); hipFree(lr.d_prims); hipFree(lr.d_meta);
+			return fail(JP_ERR_UNSUPPORTED, "jp_upload_scene: device-built BVH is deeper than the 58-entry traversal stack; hand over a host-built hierarchy for this scene");
+		}
+		c->d_nodes = lr.d_nodes; c->d_prims = lr.d_prims; c->d_meta = lr.d_meta;
+		for (int i = 0; i < s->n_primitives; i++) devPrimOf[sorted[i]] = i;
+		height = lr.height; c->build_ms = lr.build_ms;
+		n4nodes = (size_t)4 * lr.n_nodes; n4prims = (size_t)4 * s->n_primitives; nmeta = (size_t)s->n_primitives;
+	}
+	c->bvh_height = height; c->bvh_nodes = (int)(n4nodes / 4);
 
 	// tiny scenes: the flat leaf list of traverse_flat (leaf boxes padded like the node boxes, list padded to x4)
 	std::vector<float4> flat; std::vector<int> flat_leaf;
+	if (!device_build)
 	{
 		int nleaves = 0; for (int n = 0; n < s->n_bvh_nodes; n++) if (seen[n] && s->bvh_left[n] < 0) nleaves++;
 		if (nleaves <= 32)
@@ -959,9 +992,12 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16)); if (e != hipSuccess) return e;
 		return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
 	};
-	HIP_TRY(up(&c->d_nodes, nodes.data(), nodes.size() * sizeof(float4)));
-	HIP_TRY(up(&c->d_prims, prims.data(), prims.size() * sizeof(float4)));
-	HIP_TRY(up(&c->d_meta, meta.data(), meta.size() * sizeof(int4)));
+	if (!device_build)
+	{
+		HIP_TRY(up(&c->d_nodes, nodes.data(), nodes.size() * sizeof(float4)));
+		HIP_TRY(up(&c->d_prims, prims.data(), prims.size() * sizeof(float4)));
+		HIP_TRY(up(&c->d_meta, meta.data(), meta.size() * sizeof(int4)));
+	}
 	HIP_TRY(up(&c->d_mats, mats.data(), mats.size() * sizeof(float4)));
 	HIP_TRY(up(&c->d_mat_type, mtype.data(), mtype.size() * sizeof(int)));
 	HIP_TRY(up(&c->d_lights, lights.data(), lights.size() * sizeof(float4)));
@@ -969,8 +1005,8 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	if (!flat.empty()) { HIP_TRY(up(&c->d_flat, flat.data(), flat.size() * sizeof(float4))); HIP_TRY(up(&c->d_flat_leaf, flat_leaf.data(), flat_leaf.size() * sizeof(int))); }
 
 	SceneView& v = c->sv;
-	v.nodes = (const float4*)c->d_nodes; v.n_nodes = (int)nodes.size() / 4;
-	v.prims = (const float4*)c->d_prims; v.meta = (const int4*)c->d_meta; v.n_prims = (int)meta.size();
+	v.nodes = (const float4*)c->d_nodes; v.n_nodes = (int)(n4nodes / 4);
+	v.prims = (const float4*)c->d_prims; v.meta = (const int4*)c->d_meta; v.n_prims = (int)nmeta;
 	v.mats = (const float4*)c->d_mats; v.mat_type = (const int*)c->d_mat_type; v.n_mats = s->n_materials;
 	v.lights = (const float4*)c->d_lights; v.n_lights = s->n_lights;
 	v.env_sum = make_float3(envsum[0], envsum[1], envsum[2]); v.n_env = nenv;
@@ -978,10 +1014,10 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.flat = (const float4*)c->d_flat; v.flat_leaf = (const int*)c->d_flat_leaf; v.n_flat = (int)flat_leaf.size();
 	v.wide = (const uint4*)c->d_wide; v.n_wide = (int)(wide.size() / 20);
 	c->stack_depth = std::max(2, height + 2);
-	size_t scene_bytes = (nodes.size() + prims.size()) / 4 * 5 * sizeof(float4);   // 80-byte LDS record stride
-	size_t prim_bytes = prims.size() / 4 * 5 * sizeof(float4);
+	size_t scene_bytes = (n4nodes + n4prims) / 4 * 5 * sizeof(float4);   // 80-byte LDS record stride
+	size_t prim_bytes = n4prims / 4 * 5 * sizeof(float4);
 	size_t stack_bytes = (size_t)c->stack_depth * JP_BLOCK * sizeof(int);
-	c->scene_in_lds = scene_bytes + stack_bytes <= 40 * 1024;
+	c->scene_in_lds = !device_build && scene_bytes + stack_bytes <= 40 * 1024;   // device-built trees are indexed sparsely (Karras numbering): global memory only
 	c->trav_mode = use_wide ? 3 : ((!flat.empty() && prim_bytes <= 40 * 1024) ? 2 : (c->scene_in_lds ? 1 : 0));
 	if (!use_wide) if (const char* e = getenv("JETPBRT_TRAVERSAL")) { int m = atoi(e); if (m == 0 || (m == 1 && c->scene_in_lds)) c->trav_mode = m; }   // experiments: force a lower mode
 	if (use_wide) c->scene_in_lds = false;
@@ -994,7 +1030,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	{
 		size_t tab = ((size_t)2 * s->n_lights + (size_t)4 * s->n_materials) * sizeof(float4) + (size_t)s->n_materials * sizeof(int) + 16;
 		c->tables_in_lds = tab <= 16 * 1024;
-		c->shade_lds_bytes = c->tables_in_lds ? tab + (c->scene_in_lds ? prims.size() * sizeof(float4) + meta.size() * sizeof(int4) : 0) : 0;
+		c->shade_lds_bytes = c->tables_in_lds ? tab + (c->scene_in_lds ? n4prims * sizeof(float4) + nmeta * sizeof(int4) : 0) : 0;
 		c->stage_nee = c->tables_in_lds && std::max(1, planes) <= 4;
 		if (c->stage_nee) c->shade_lds_bytes += 16 + (size_t)std::max(1, planes) * 2 * JP_BLOCK * sizeof(float4);
 	}
@@ -1187,6 +1223,14 @@ int jp_get_counters(JpContext* c, JpCounters* out)
 	if (!c || !out) return fail(JP_ERR_INVALID_ARGUMENT, "jp_get_counters: null argument");
 	int st = finish_counters(c); if (st != JP_OK) return st;
 	*out = c->counters; return JP_OK;
+}
+int jp_get_build_info(JpContext* c, JpBuildInfo* out)
+{
+	if (!c || !out) return fail(JP_ERR_INVALID_ARGUMENT, "jp_get_build_info: null argument");
+	if (!c->have_scene) return fail(JP_ERR_NO_SCENE, "jp_get_build_info: no scene uploaded");
+	out->built_on_device = c->build_on_device ? 1 : 0; out->traversal_mode = c->trav_mode; out->bvh_nodes = c->bvh_nodes; out->bvh_height = c->bvh_height;
+	out->device_build_ms = c->build_ms;
+	return JP_OK;
 }
 
 int jp_trace(JpContext* c, int32_t n, const float* origin, const float* dir, const float* tmin, const float* tmax, int32_t* hit, float* t, int32_t* prim, float* normal)

@@ -1,0 +1,296 @@
+// jet-pbrt_amd/csrc/jp_lbvh.h -- device-side hierarchy build.
+//
+// Replaces the host-side tree build of FScene::Preprocess (scene.cc:11-23 -> FBVH_NodeBase::Build, bvh.cc:23-84) for
+// scenes handed over WITHOUT a hierarchy (JpScene.n_bvh_nodes == 0): the primitive records are uploaded in creation
+// order and the tree is built where it is used.  Closest-hit / occlusion results do not depend on the topology
+// (SURVEY.md section 7), so the film is the same as with the host-built SAH tree up to the tie-break between
+// coincident surfaces.
+//
+// Pipeline (all on the context stream, no host round trip until the final height read-back):
+//   k_lbvh_bounds   exact extent of every primitive + scene extent (wave-reduced, ordered-uint atomics)
+//   k_lbvh_morton   63-bit Morton code of the box centre (21 bits per axis)
+//   hipcub radix sort (key = code, value = primitive)
+//   k_lbvh_gather   primitive records / meta / boxes into sorted order (= device primitive order)
+//   k_lbvh_hier     Karras 2012: one thread per interior node finds its range and split (duplicate codes are
+//                   disambiguated by index, so the tree is a function of the sorted order alone)
+//   k_lbvh_refit    bottom-up: the second thread to arrive at a node joins the child boxes and writes the device
+//                   node record (children boxes in the parent, padded like the host path); subtrees of <= maxLeaf
+//                   primitives collapse into one leaf (their primitives are contiguous in sorted order)
+//   k_lbvh_depth    height of the emitted tree (sizes the per-lane LDS traversal stack)
+#ifndef JP_LBVH_H
+#define JP_LBVH_H
+#include <hipcub/hipcub.hpp>
+
+__device__ __forceinline__ unsigned int lbvh_ord(float f) { const unsigned int b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float lbvh_unord(unsigned int u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+__global__ void k_lbvh_init(unsigned int* scene6, int* height)
+{
+	if (threadIdx.x < 3) scene6[threadIdx.x] = 0xffffffffu; else if (threadIdx.x < 6) scene6[threadIdx.x] = 0u;
+	if (threadIdx.x == 6) *height = 0;
+}
+
+__global__ void __launch_bounds__(256) k_lbvh_bounds(const float4* __restrict__ prims0, int n, float4* __restrict__ lo, float4* __restrict__ hi, unsigned int* scene6)
+{
+	const int p = blockIdx.x * 256 + threadIdx.x;
+	float l[3] = { 3e38f, 3e38f, 3e38f }, h[3] = { -3e38f, -3e38f, -3e38f };
+	if (p < n)
+	{
+		const float4 g0 = prims0[4 * p], g1 = prims0[4 * p + 1], g2 = prims0[4 * p + 2], g3 = prims0[4 * p + 3];
+		const int type = __float_as_int(g3.w);
+		if (type == JP_SHAPE_SPHERE)
+		{
+			l[0] = g0.x - g0.w; l[1] = g0.y - g0.w; l[2] = g0.z - g0.w; h[0] = g0.x + g0.w; h[1] = g0.y + g0.w; h[2] = g0.z + g0.w;
+		}
+		else
+		{
+			l[0] = fminf(fminf(g0.x, g1.x), g2.x); l[1] = fminf(fminf(g0.y, g1.y), g2.y); l[2] = fminf(fminf(g0.z, g1.z), g2.z);
+			h[0] = fmaxf(fmaxf(g0.x, g1.x), g2.x); h[1] = fmaxf(fmaxf(g0.y, g1.y), g2.y); h[2] = fmaxf(fmaxf(g0.z, g1.z), g2.z);
+			if (type == JP_SHAPE_RECTANGLE)
+			{
+				l[0] = fminf(l[0], g0.w); l[1] = fminf(l[1], g1.w); l[2] = fminf(l[2], g2.w);
+				h[0] = fmaxf(h[0], g0.w); h[1] = fmaxf(h[1], g1.w); h[2] = fmaxf(h[2], g2.w);
+			}
+		}
+		lo[p] = make_float4(l[0], l[1], l[2], 0); hi[p] = make_float4(h[0], h[1], h[2], 0);
+	}
+	#pragma unroll
+	for (int a = 0; a < 3; a++)
+	{
+		float vl = l[a], vh = h[a];
+		for (int off = 32; off > 0; off >>= 1) { vl = fminf(vl, __shfl_xor(vl, off)); vh = fmaxf(vh, __shfl_xor(vh, off)); }
+		if ((threadIdx.x & 63) == 0 && vl <= vh) { atomicMin(&scene6[a], lbvh_ord(vl)); atomicMax(&scene6[3 + a], lbvh_ord(vh)); }
+	}
+}
+
+__device__ __forceinline__ unsigned long long lbvh_spread21(unsigned int v)
+{
+	unsigned long long x = v & 0x1fffffu;
+	x = (x | (x << 32)) & 0x1f00000000ffffull;
+	x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+	x = (x | (x << 8)) & 0x100f00f00f00f00full;
+	x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+	x = (x | (x << 2)) & 0x1249249249249249ull;
+	return x;
+}
+
+__global__ void __launch_bounds__(256) k_lbvh_morton(const float4* __restrict__ lo, const float4* __restrict__ hi, int n, const unsigned int* __restrict__ scene6,
+                                                     unsigned long long* __restrict__ keys, int* __restrict__ vals)
+{
+	const int p = blockIdx.x * 256 + threadIdx.x;
+	if (p >= n) return;
+	const float4 l = lo[p], h = hi[p];
+	const float c[3] = { 0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z) };
+	unsigned int q[3];
+	#pragma unroll
+	for (int a = 0; a < 3; a++)
+	{
+		const float sl = lbvh_unord(scene6[a]), sh = lbvh_unord(scene6[3 + a]);
+		const float ext = sh - sl;
+		float t = ext > 0.f ? (c[a] - sl) / ext : 0.f;
+		t = fminf(fmaxf(t, 0.f), 1.f) * 2097152.f;
+		q[a] = (unsigned int)fminf(t, 2097151.f);
+	}
+	keys[p] = (lbvh_spread21(q[0]) << 2) | (lbvh_spread21(q[1]) << 1) | lbvh_spread21(q[2]);
+	vals[p] = p;
+}
+
+__global__ void __launch_bounds__(256) k_lbvh_gather(const int* __restrict__ order, int n, const float4* __restrict__ prims0, const int4* __restrict__ meta0,
+                                                     const float4* __restrict__ lo0, const float4* __restrict__ hi0,
+                                                     float4* __restrict__ prims, int4* __restrict__ meta, float4* __restrict__ lo, float4* __restrict__ hi)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	const int p = order[i];
+	prims[4 * i] = prims0[4 * p]; prims[4 * i + 1] = prims0[4 * p + 1]; prims[4 * i + 2] = prims0[4 * p + 2]; prims[4 * i + 3] = prims0[4 * p + 3];
+	meta[i] = meta0[p]; lo[i] = lo0[p]; hi[i] = hi0[p];
+}
+
+// length of the common prefix of the (code, index) keys of sorted positions i and j; -1 outside the array
+__device__ __forceinline__ int lbvh_delta(const unsigned long long* __restrict__ keys, int n, int i, int j)
+{
+	if (j < 0 || j >= n) return -1;
+	const unsigned long long x = keys[i] ^ keys[j];
+	return x ? __clzll((long long)x) : 64 + __clz(i ^ j);
+}
+
+// child encoding in childL / childR: >= 0 interior node, < 0 leaf of sorted position -(c) - 1
+__global__ void __launch_bounds__(256) k_lbvh_hier(const unsigned long long* __restrict__ keys, int n, int* __restrict__ childL, int* __restrict__ childR,
+                                                   int* __restrict__ parentI, int* __restrict__ parentL, int* __restrict__ first, int* __restrict__ last)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n - 1) return;
+	const int d = lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+	const int dmin = lbvh_delta(keys, n, i, i - d);
+	int lmax = 2;
+	while (lbvh_delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+	int l = 0;
+	for (int t = lmax >> 1; t >= 1; t >>= 1) if (lbvh_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+	const int j = i + l * d;
+	const int dnode = lbvh_delta(keys, n, i, j);
+	int s = 0;
+	for (int t = (l + 1) >> 1; ; t = (t + 1) >> 1)
+	{
+		if (lbvh_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+		if (t == 1) break;
+	}
+	const int gamma = i + s * d + (d < 0 ? -1 : 0);
+	const int f = i < j ? i : j, e = i < j ? j : i;
+	first[i] = f; last[i] = e;
+	if (gamma == f) { childL[i] = -gamma - 1; parentL[gamma] = i; } else { childL[i] = gamma; parentI[gamma] = i; }
+	if (gamma + 1 == e) { childR[i] = -(gamma + 1) - 1; parentL[gamma + 1] = i; } else { childR[i] = gamma + 1; parentI[gamma + 1] = i; }
+}
+
+__device__ __forceinline__ void lbvh_store4(float4* p, float4 v)
+{
+	float* f = (float*)p;
+	__hip_atomic_store(f + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(f + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__hip_atomic_store(f + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 lbvh_load4(const float4* p)
+{
+	float* f = (float*)p; float4 v;
+	v.x = __hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.y = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	v.z = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.w = 0.f;
+	return v;
+}
+// the relative pad of the host path (jp_upload_scene pad_box): >> ulp, keeps zero-extent boxes hittable
+__device__ __forceinline__ void lbvh_pad(float& l, float& h)
+{
+	const float m = fmaxf(fabsf(l), fabsf(h)); const float e = m * 1e-6f + 1e-6f;
+	l = l - e; h = h + e;
+}
+
+__global__ void __launch_bounds__(256) k_lbvh_refit(int n, int maxLeaf, const int* __restrict__ childL, const int* __restrict__ childR, const int* __restrict__ parentI,
+                                                    const int* __restrict__ parentL, const int* __restrict__ first, const int* __restrict__ last,
+                                                    const float4* __restrict__ leafLo, const float4* __restrict__ leafHi, float4* nodeLo, float4* nodeHi,
+                                                    unsigned int* flag, float4* __restrict__ nodes)
+{
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= n) return;
+	int node = parentL[j];
+	for (;;)
+	{
+		if (atomicAdd(&flag[node], 1u) == 0u) return;          // the first arrival leaves; the second finds both children complete
+		__threadfence();
+		float4 bl[2], bh[2]; int ref[2];
+		#pragma unroll
+		for (int k = 0; k < 2; k++)
+		{
+			const int c = k == 0 ? childL[node] : childR[node];
+			if (c < 0) { const int leaf = -c - 1; bl[k] = leafLo[leaf]; bh[k] = leafHi[leaf]; ref[k] = -((leaf << 4) + 1); }
+			else
+			{
+				bl[k] = lbvh_load4(&nodeLo[c]); bh[k] = lbvh_load4(&nodeHi[c]);
+				const int cnt = last[c] - first[c] + 1;
+				ref[k] = cnt <= maxLeaf ? -(((first[c] << 4) | (cnt - 1)) + 1) : c;
+			}
+		}
+		lbvh_store4(&nodeLo[node], make_float4(fminf(bl[0].x, bl[1].x), fminf(bl[0].y, bl[1].y), fminf(bl[0].z, bl[1].z), 0));
+		lbvh_store4(&nodeHi[node], make_float4(fmaxf(bh[0].x, bh[1].x), fmaxf(bh[0].y, bh[1].y), fmaxf(bh[0].z, bh[1].z), 0));
+		if (node == 0 || last[node] - first[node] + 1 > maxLeaf)
+		{
+			lbvh_pad(bl[0].x, bh[0].x); lbvh_pad(bl[0].y, bh[0].y); lbvh_pad(bl[0].z, bh[0].z);
+			lbvh_pad(bl[1].x, bh[1].x); lbvh_pad(bl[1].y, bh[1].y); lbvh_pad(bl[1].z, bh[1].z);
+			nodes[4 * node + 0] = make_float4(bl[0].x, bl[0].y, bl[0].z, bh[0].x);
+			nodes[4 * node + 1] = make_float4(bh[0].y, bh[0].z, bl[1].x, bl[1].y);
+			nodes[4 * node + 2] = make_float4(bl[1].z, bh[1].x, bh[1].y, bh[1].z);
+			nodes[4 * node + 3] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), 0, 0);
+		}
+		if (node == 0) return;
+		__threadfence();
+		node = parentI[node];
+	}
+}
+
+// emitted interior nodes on the path root -> leaf (the traversal stack never holds more entries than that)
+__global__ void __launch_bounds__(256) k_lbvh_depth(int n, int maxLeaf, const int* __restrict__ parentI, const int* __restrict__ parentL,
+                                                    const int* __restrict__ first, const int* __restrict__ last, int* height)
+{
+	const int j = blockIdx.x * 256 + threadIdx.x;
+	int h = 0;
+	if (j < n)
+		for (int node = parentL[j];; node = parentI[node])
+		{
+			if (node == 0 || last[node] - first[node] + 1 > maxLeaf) h++;
+			if (node == 0) break;
+		}
+	for (int off = 32; off > 0; off >>= 1) h = max(h, __shfl_xor(h, off));
+	if ((threadIdx.x & 63) == 0 && h > 0) atomicMax(height, h);
+}
+
+// a single primitive: synthetic interior root whose right child can never be hit (as the host path does)
+__global__ void k_lbvh_single(const float4* __restrict__ lo, const float4* __restrict__ hi, float4* __restrict__ nodes)
+{
+	float4 l = lo[0], h = hi[0];
+	lbvh_pad(l.x, h.x); lbvh_pad(l.y, h.y); lbvh_pad(l.z, h.z);
+	const int ref = -1;                                        // leaf: first primitive 0, count 1
+	nodes[0] = make_float4(l.x, l.y, l.z, h.x); nodes[1] = make_float4(h.y, h.z, 1e30f, 1e30f);
+	nodes[2] = make_float4(1e30f, -1e30f, -1e30f, -1e30f); nodes[3] = make_float4(__int_as_float(ref), __int_as_float(ref), 0, 0);
+}
+
+struct LbvhResult { void* d_nodes = nullptr; void* d_prims = nullptr; void* d_meta = nullptr; int n_nodes = 0, height = 0; float build_ms = 0.f; };
+
+// prims0 / meta0: device arrays in creation order (4 x float4 and one int4 per primitive).  On success the caller
+// owns r.d_nodes / d_prims / d_meta and `order` holds, for each device (sorted) position, the creation-order index.
+static hipError_t lbvh_build(hipStream_t stream, const float4* prims0, const int4* meta0, int n, int maxLeaf, LbvhResult& r, std::vector<int>& order)
+{
+	hipError_t e = hipSuccess;
+	std::vector<void*> tmp;
+	auto dalloc = [&](void** p, size_t bytes, bool keep) -> bool { e = hipMalloc(p, std::max<size_t>(bytes, 16)); if (e != hipSuccess) return false; if (!keep) tmp.push_back(*p); return true; };
+	auto cleanup = [&]() { for (void* p : tmp) hipFree(p); };
+	auto bail = [&]() { cleanup(); if (r.d_nodes) hipFree(r.d_nodes); if (r.d_prims) hipFree(r.d_prims); if (r.d_meta) hipFree(r.d_meta); r = LbvhResult(); return e; };
+	float4 *lo0, *hi0, *lo, *hi, *nlo, *nhi; unsigned long long *keys, *keys2; int *vals, *vals2, *childL, *childR, *parentI, *parentL, *first, *last, *height;
+	unsigned int *scene6, *flag; void* sorttmp = nullptr; size_t sortbytes = 0;
+	const size_t N = (size_t)n, NI = (size_t)std::max(1, n - 1);
+	if (!dalloc((void**)&lo0, N * 16, false) || !dalloc((void**)&hi0, N * 16, false) || !dalloc((void**)&lo, N * 16, false) || !dalloc((void**)&hi, N * 16, false)
+	    || !dalloc((void**)&nlo, NI * 16, false) || !dalloc((void**)&nhi, NI * 16, false) || !dalloc((void**)&keys, N * 8, false) || !dalloc((void**)&keys2, N * 8, false)
+	    || !dalloc((void**)&vals, N * 4, false) || !dalloc((void**)&vals2, N * 4, false) || !dalloc((void**)&childL, NI * 4, false) || !dalloc((void**)&childR, NI * 4, false)
+	    || !dalloc((void**)&parentI, NI * 4, false) || !dalloc((void**)&parentL, N * 4, false) || !dalloc((void**)&first, NI * 4, false) || !dalloc((void**)&last, NI * 4, false)
+	    || !dalloc((void**)&scene6, 32, false) || !dalloc((void**)&height, 16, false) || !dalloc((void**)&flag, NI * 4, false)
+	    || !dalloc(&r.d_nodes, NI * 64, true) || !dalloc(&r.d_prims, N * 64, true) || !dalloc(&r.d_meta, N * 16, true))
+		return bail();
+	if ((e = hipcub::DeviceRadixSort::SortPairs(nullptr, sortbytes, keys, keys2, vals, vals2, n, 0, 63, stream)) != hipSuccess) return bail();
+	if (!dalloc(&sorttmp, sortbytes, false)) return bail();
+	hipEvent_t e0, e1;
+	if ((e = hipEventCreate(&e0)) != hipSuccess) return bail();
+	if ((e = hipEventCreate(&e1)) != hipSuccess) { hipEventDestroy(e0); return bail(); }
+	const int grid = (n + 255) / 256;
+	hipEventRecord(e0, stream);
+	hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, stream, scene6, height);
+	hipMemsetAsync(flag, 0, NI * 4, stream);
+	hipMemsetAsync(r.d_nodes, 0, NI * 64, stream);
+	hipLaunchKernelGGL(k_lbvh_bounds, dim3(grid), dim3(256), 0, stream, prims0, n, lo0, hi0, scene6);
+	if (n == 1)
+	{
+		hipLaunchKernelGGL(k_lbvh_single, dim3(1), dim3(1), 0, stream, (const float4*)lo0, (const float4*)hi0, (float4*)r.d_nodes);
+		hipMemcpyAsync(r.d_prims, prims0, 64, hipMemcpyDeviceToDevice, stream); hipMemcpyAsync(r.d_meta, meta0, 16, hipMemcpyDeviceToDevice, stream);
+		order.assign(1, 0); r.n_nodes = 1; r.height = 1;
+	}
+	else
+	{
+		hipLaunchKernelGGL(k_lbvh_morton, dim3(grid), dim3(256), 0, stream, (const float4*)lo0, (const float4*)hi0, n, (const unsigned int*)scene6, keys, vals);
+		if ((e = hipcub::DeviceRadixSort::SortPairs(sorttmp, sortbytes, keys, keys2, vals, vals2, n, 0, 63, stream)) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return bail(); }
+		hipLaunchKernelGGL(k_lbvh_gather, dim3(grid), dim3(256), 0, stream, (const int*)vals2, n, prims0, meta0, (const float4*)lo0, (const float4*)hi0, (float4*)r.d_prims, (int4*)r.d_meta, lo, hi);
+		hipLaunchKernelGGL(k_lbvh_hier, dim3(grid), dim3(256), 0, stream, (const unsigned long long*)keys2, n, childL, childR, parentI, parentL, first, last);
+		hipLaunchKernelGGL(k_lbvh_refit, dim3(grid), dim3(256), 0, stream, n, maxLeaf, (const int*)childL, (const int*)childR, (const int*)parentI, (const int*)parentL,
+		                   (const int*)first, (const int*)last, (const float4*)lo, (const float4*)hi, nlo, nhi, flag, (float4*)r.d_nodes);
+		hipLaunchKernelGGL(k_lbvh_depth, dim3(grid), dim3(256), 0, stream, n, maxLeaf, (const int*)parentI, (const int*)parentL, (const int*)first, (const int*)last, height);
+		r.n_nodes = n - 1;
+	}
+	hipEventRecord(e1, stream);
+	if (n > 1)
+	{
+		order.resize(N);
+		if ((e = hipMemcpyAsync(order.data(), vals2, N * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return bail(); }
+		if ((e = hipMemcpyAsync(&r.height, height, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return bail(); }
+	}
+	e = hipStreamSynchronize(stream);
+	if (e == hipSuccess) e = hipGetLastError();
+	if (e == hipSuccess) hipEventElapsedTime(&r.build_ms, e0, e1);
+	hipEventDestroy(e0); hipEventDestroy(e1);
+	if (e != hipSuccess) return bail();
+	cleanup();
+	return hipSuccess;
+}
+#endif

@@ -253,8 +253,12 @@ public:
 	std::vector<std::shared_ptr<FLight>> lights;
 	std::vector<std::shared_ptr<FPrimitive>> primitives;
 	FBounds3 worldBound;
-	FlatBVH bvh;                                                 // built by Preprocess()
+	FlatBVH bvh;                                                 // built by Preprocess() unless deviceBuild
 	bool preprocessed = false;
+	// true: Preprocess() skips the host SAH build and the flattened scene carries no hierarchy (n_bvh_nodes = 0), so
+	// jp_upload_scene builds an LBVH on the device.  Setup drops from ~0.3 s to a few ms on the 280k-triangle scene at
+	// the price of a lower-quality tree: meant for previews / low spp.  Default from env JETPBRT_DEVICE_BVH=1.
+	bool deviceBuild = false;
 };
 
 // binned-SAH BVH over primitive bounds -> the flat node arrays of JpScene (own topology)

@@ -208,6 +208,8 @@ void FScene::Preprocess()                                                // scen
 	for (auto& p : primitives) bound.Expand(p->shape->WorldBounds());     // scene.cc:35-45
 	worldBound = bound;
 	for (auto& l : lights) l->Preprocess(*this);
+	if (const char* e = getenv("JETPBRT_DEVICE_BVH")) if (atoi(e) == 1) deviceBuild = true;
+	if (deviceBuild) { bvh = FlatBVH(); preprocessed = true; return; }
 	std::vector<FBounds3> pb; pb.reserve(primitives.size());
 	// own BVH over the exact extents: a ray leaving a flat surface (min_t 0.001) or ending 0.001 short of a light
 	// then misses that surface's box instead of visiting its leaf through the reference's 0.01 thinness pad
@@ -297,7 +299,8 @@ bool FlattenScene(const FScene& scene, FlatScene& out, std::string* error)
 	v.n_materials = (int)out.mat_type.size(); v.mat_type = out.mat_type.data(); v.mat_params = out.mat_params.data();
 	v.n_lights = (int)out.light_type.size(); v.light_type = out.light_type.data(); v.light_radiance = out.light_radiance.data(); v.light_prim = out.light_prim.data(); v.light_vec = out.light_vec.data();
 	v.world_radius = worldRadius;
-	v.n_bvh_nodes = (int)out.bvh.left.size(); v.bvh_bounds = out.bvh.bounds.data(); v.bvh_left = out.bvh.left.data(); v.bvh_right = out.bvh.right.data();
+	v.n_bvh_nodes = (int)out.bvh.left.size();                    // 0: hierarchy to be built on the device
+	v.bvh_bounds = out.bvh.bounds.data(); v.bvh_left = out.bvh.left.data(); v.bvh_right = out.bvh.right.data();
 	v.n_bvh_prim_indices = (int)out.bvh.prim_index.size(); v.bvh_prim_index = out.bvh.prim_index.data();
 	return true;
 }

@@ -226,6 +226,10 @@ class HostBackend:
     def preprocess(self):
         self._f("scene_preprocess")(self.h)
 
+    def set_device_build(self, on=True):
+        """FScene::deviceBuild: leave the hierarchy to jp_upload_scene's device LBVH pass (host backend only)."""
+        self._f("scene_set_device_build")(self.h, 1 if on else 0)
+
     def num_primitives(self):
         return self._f("num_primitives")(self.h)
 

@@ -346,3 +346,125 @@ def test_wide_bvh_closest_hit_records(H, gpu_ctx, tmp_path, monkeypatch):
         assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)) and (prim == oprim).mean() > 0.9999, wide
     monkeypatch.delenv("JETPBRT_TRACE_WIDE")
     assert ohit.mean() > 0.3
+
+
+# ---- device-side hierarchy build (jet-pbrt_amd/csrc/jp_lbvh.h) ----------------------------
+def _oracle_trace(H, sp, o, d, tmin, tmax):
+    m = o.shape[0]
+    L = H.oracle_lib(); oh = L.jp_oracle_scene_new(sp)
+    ohit = np.zeros(m, np.int32); ot = np.zeros(m, np.float32); oprim = np.zeros(m, np.int32); onrm = np.zeros((m, 3), np.float32); opos = np.zeros((m, 3), np.float32)
+    L.jp_oracle_trace(oh, m, H.ptr(o), H.ptr(d), H.ptr(tmin), H.ptr(tmax), H.ptr(ohit), H.ptr(ot), H.ptr(oprim), H.ptr(onrm), H.ptr(opos))
+    L.jp_oracle_scene_free(oh)
+    return ohit, ot, oprim, onrm
+
+
+def _device_built(H, name, W, Hh):
+    hb = H.scenes.HostBackend(name)
+    hb.set_device_build(True)                                   # FScene::deviceBuild: Preprocess() leaves the tree to the device
+    H.SCENES[name](hb, W, Hh)
+    sp = hb.flatten()
+    assert sp.contents.n_bvh_nodes == 0 and sp.contents.n_primitives > 0
+    return hb, sp
+
+
+@pytest.mark.parametrize("name", SCENE_NAMES)
+def test_device_built_hierarchy_records_and_film(H, gpu_ctx, name):
+    """no hierarchy handed over -> jp_upload_scene builds an LBVH on the device: hit records bit-exact vs the oracle's
+    reference-style tree, film within the gate, and the same film as with the host-built SAH tree up to tie-breaks"""
+    W = Hh = 48
+    hb, sp = _device_built(H, name, W, Hh)
+    gpu_ctx.upload(sp)
+    bi = gpu_ctx.build_info()
+    assert bi.built_on_device == 1 and bi.traversal_mode == 0 and bi.bvh_height >= 1 and bi.device_build_ms > 0
+    rng = np.random.default_rng(17)
+    m = 100000
+    o = (rng.random((m, 3)) * [500, 500, 500] + [25, 25, -530]).astype(np.float32)
+    if name == "bunny_small":
+        o = (rng.random((m, 3)) * [500, 300, 500] - [250, -10, 250]).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[: m // 50, 0] = 0.0
+    d[m // 50: m // 25, 2] = 0.0
+    tmin = np.full(m, 0.001, np.float32); tmax = np.where(rng.random(m) < 0.5, np.inf, rng.random(m) * 400).astype(np.float32)
+    hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
+    ohit, ot, oprim, onrm = _oracle_trace(H, sp, o, d, tmin, tmax)
+    assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    same = prim == oprim
+    assert same.mean() > 0.9999 and np.array_equal(nrm[same].view(np.uint32), onrm[same].view(np.uint32))
+    p = H.jp.render_params(W, Hh, 8, 5, 1234)
+    film = gpu_ctx.render(p)
+    ref, cnt = H.oracle_render(sp, p, 4)
+    assert l2(film, ref) < TOL_L2, l2(film, ref)
+    c = gpu_ctx.counters()
+    assert abs(c.closest_rays - cnt.closest_rays) <= max(8, cnt.closest_rays * 5e-4)
+    hb2, sp2 = _scene(H, name, W, Hh)                             # host-built SAH tree, same scene
+    gpu_ctx.upload(sp2)
+    assert gpu_ctx.build_info().built_on_device == 0
+    assert l2(film, gpu_ctx.render(p)) < TOL_L2
+
+
+def test_device_built_hierarchy_edge_cases(H, gpu_ctx, tmp_path):
+    """one primitive (synthetic root), two primitives, many coincident primitives (identical Morton codes: the index
+    tie-break keeps the tree well-formed), a 2000-triangle soup against the oracle"""
+    S = H.scenes
+
+    def build(extra):
+        hb = S.HostBackend("edge"); hb.set_device_build(True)
+        hb.camera((0, 0, 9), (0, 0, -1), (0, 1, 0), 55.0, 40, 40)
+        hb.envlight((0.4, 0.5, 0.6))
+        m = hb.mat_matte((0.6, 0.5, 0.4))
+        extra(hb, m)
+        hb.preprocess()
+        return hb, hb.flatten()
+
+    cases = {
+        "one": lambda hb, m: hb.rect(S.AXIS_XY, -2, 2, -2, 2, 0.0, False, m, None),
+        "two": lambda hb, m: (hb.rect(S.AXIS_XY, -2, 2, -2, 2, 0.0, False, m, None), hb.sphere((0, 0, 2), 0.7, m, (4.0, 4.0, 4.0))),
+        "coincident": lambda hb, m: [hb.rect(S.AXIS_XY, -2, 2, -2, 2, -1.0, False, m, None) for _ in range(37)] + [hb.sphere((1, 1, 1), 0.5, m, None) for _ in range(9)],
+    }
+    rng = np.random.default_rng(3)
+    n = 20000
+    o = rng.uniform(-3, 3, (n, 3)).astype(np.float32); o[:, 2] = 8.0
+    d = np.tile(np.array([[0, 0, -1]], np.float32), (n, 1)) + rng.normal(0, 0.05, (n, 3)).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    tmin = np.full(n, 0.001, np.float32); tmax = np.full(n, np.inf, np.float32)
+    for tag, fn in cases.items():
+        hb, sp = build(fn)
+        gpu_ctx.upload(sp)
+        assert gpu_ctx.build_info().built_on_device == 1
+        hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
+        ohit, ot, oprim, onrm = _oracle_trace(H, sp, o, d, tmin, tmax)
+        assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)), tag
+        assert hit.mean() > 0.2, tag
+        p = H.jp.render_params(40, 40, 4, 5, 7)
+        ref, _ = H.oracle_render(sp, p, 2)
+        assert l2(gpu_ctx.render(p), ref) < TOL_L2, tag
+    hb = S.HostBackend("soup"); hb.set_device_build(True)
+    H.build_random_scene(hb, 64, 48, 21, n_tris=2000, tmpdir=str(tmp_path))
+    sp = hb.flatten()
+    gpu_ctx.upload(sp)
+    m = 100000
+    o = rng.uniform(-4, 4, (m, 3)).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    tmin = np.full(m, 0.001, np.float32); tmax = np.where(rng.random(m) < 0.5, np.inf, rng.random(m) * 6).astype(np.float32)
+    hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
+    ohit, ot, oprim, onrm = _oracle_trace(H, sp, o, d, tmin, tmax)
+    assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)) and (prim == oprim).mean() > 0.9999
+    p = H.jp.render_params(64, 48, 8, 5, 3)
+    ref, _ = H.oracle_render(sp, p, 8)
+    assert l2(gpu_ctx.render(p), ref) < TOL_L2
+
+
+def test_device_built_hierarchy_bunny(H, gpu_ctx):
+    """the 280k-triangle scene with the tree built on the device: film within the gate of the oracle's"""
+    W, Hh, spp = 160, 120, 2
+    hb = H.scenes.HostBackend("bunny"); hb.set_device_build(True)
+    H.scenes.build_bunny(hb, W, Hh)
+    sp = hb.flatten()
+    assert sp.contents.n_bvh_nodes == 0
+    gpu_ctx.upload(sp)
+    bi = gpu_ctx.build_info()
+    assert bi.built_on_device == 1 and bi.bvh_nodes == sp.contents.n_primitives - 1
+    p = H.jp.render_params(W, Hh, spp)
+    film = gpu_ctx.render(p)
+    ref, cnt = H.oracle_render(sp, p, len(os.sched_getaffinity(0)))
+    assert l2(film, ref) < TOL_L2, l2(film, ref)
