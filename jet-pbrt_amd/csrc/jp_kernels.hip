@@ -350,9 +350,16 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 					const int mtype = mat_type[mat];
 					if (mtype == JP_MAT_PLASTIC) up = jp_rng_float(key, dim++);   // material.cc:14
 					make_closure(mats, mtype, mat, up, c);
+#ifdef JP_DBG_SKIP_FRAME
+					fr.n = N; fr.s = mk(N.y, N.z, N.x); fr.t = mk(N.z, N.x, N.y);
+#else
 					fr = frame_from_z(N);
+#endif
 					shaded = true;
 					wantNee = !is_delta(c);
+#ifdef JP_DBG_SKIP_NEE
+					wantNee = false;
+#endif
 				}
 			}
 		}
@@ -401,7 +408,11 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				if (!kStage) q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
 			}
 		}
+#ifdef JP_DBG_SKIP_SAMPLE
+		if (false)
+#else
 		if (shaded)
+#endif
 		{
 			// ---- BSDF sample (integrator.cc:375-379) ----
 			const float ux = jp_rng_float(key, dim), uy = jp_rng_float(key, dim + 1); dim += 2;
