@@ -30,8 +30,8 @@ def test_abi_struct_layout_matches_header(H):
     #include "jetpbrt_amd.h"
     #include <stdio.h>
     #include <stddef.h>
-    int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(JpScene), sizeof(JpRenderParams), sizeof(JpCounters), sizeof(JpCamera),
-                offsetof(JpScene, bvh_prim_index), offsetof(JpScene, world_radius)); return 0; }'''
+    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(JpScene), sizeof(JpRenderParams), sizeof(JpCounters), sizeof(JpCamera),
+                offsetof(JpScene, bvh_prim_index), offsetof(JpScene, world_radius), sizeof(JpBuildInfo), offsetof(JpBuildInfo, device_build_ms)); return 0; }'''
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
@@ -39,7 +39,22 @@ def test_abi_struct_layout_matches_header(H):
         out = subprocess.run([os.path.join(d, "t")], check=True, stdout=subprocess.PIPE, text=True).stdout.split()
     jp = H.jp
     assert [int(v) for v in out] == [C.sizeof(jp.JpScene), C.sizeof(jp.JpRenderParams), C.sizeof(jp.JpCounters), C.sizeof(jp.JpCamera),
-                                     jp.JpScene.bvh_prim_index.offset, jp.JpScene.world_radius.offset]
+                                     jp.JpScene.bvh_prim_index.offset, jp.JpScene.world_radius.offset,
+                                     C.sizeof(jp.JpBuildInfo), jp.JpBuildInfo.device_build_ms.offset]
+
+
+def test_device_build_flag_flattens_without_a_hierarchy(H):
+    """FScene::deviceBuild: Preprocess() skips the host tree and the flattened scene says so (n_bvh_nodes == 0);
+    everything else is identical to the host-built flattening"""
+    hb = H.scenes.HostBackend("dev"); hb.set_device_build(True)
+    H.SCENES["misc"](hb, 32, 24)
+    a = hb.flatten().contents
+    hb2, b = _flat(H, "misc")
+    assert a.n_bvh_nodes == 0 and b.n_bvh_nodes > 0
+    assert a.n_primitives == b.n_primitives and a.n_lights == b.n_lights and a.world_radius == b.world_radius
+    n = a.n_primitives
+    for f in ("prim_shape_type", "prim_shape_index", "prim_material", "prim_light"):
+        assert np.array_equal(np.ctypeslib.as_array(getattr(a, f), (n,)), np.ctypeslib.as_array(getattr(b, f), (n,)))
 
 
 def test_product_does_not_reference_oracle(H):
