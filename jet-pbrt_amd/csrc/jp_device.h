@@ -219,6 +219,9 @@ __device__ __forceinline__ int traverse_flat(const float4* flat_g, int n_flat4, 
 		}
 	}
 	int hit = -1;
+#ifdef JP_DBG_FLAT_P1ONLY
+	mask = mask == 0xffffffffu ? 1u : 0u;                        // timing experiment (tools/gpu_shade_split.py): box phase only
+#endif
 	while (mask)
 	{
 		const int i = __ffs((int)mask) - 1;
