@@ -6,14 +6,16 @@
 
 A "step" is one full pass of the hot path over the workload: one frame of the synthetic Cornell-box-shaped scene
 (BASELINE.json configs[1]: 512x512, 1024 spp, Lambertian-only) rendered through the C ABI (jp_render), scene
-already resident in HBM, film download included.  At N > 1 the 20-row bands of the film
-(the reference's FRenderTask unit, integrator.cc:53) are dealt round-robin to the ranks, each rank renders its
-bands into a device film that is zero elsewhere, and ONE RCCL reduce(sum) over xGMI assembles the film on rank 0.
+already resident in HBM, film download included.  At N > 1 the row bands of the film
+(the reference's FRenderTask unit, integrator.cc:53: 20 rows; here the largest height <= 20 that deals evenly, 16 rows
+for 512 rows on 2/4/8 ranks) are dealt round-robin to the ranks, each rank renders its bands into a device film that
+is zero elsewhere, and ONE RCCL reduce(sum) over xGMI assembles the film on rank 0.
 Weak scaling: the sample count grows with N (spp = 1024 * N), so every GPU traces the same number of paths as in
 the 1-GPU run.
 
 Rank 0 prints one JSON line.  Besides the contract fields it carries
-  roofline     : dominant kernel class, algorithmic bytes per launch / HIP-event launch duration vs 8 TB/s HBM
+  roofline     : dominant kernel class, algorithmic bytes per launch / HIP-event launch duration (events on the kernel
+                 stream, taken on the last step of the timed region) vs 8 TB/s HBM
   cpu_baseline : the oracle restatement of the reference CPU path timed on this box's host cores on a bounded
                  sample (whole 20-row bands at the full spp), which is also the parity sample (l2_vs_cpu_ref)
 """
@@ -81,7 +83,11 @@ def main():
     scene = be.flatten()
     ctx = jp.Context(dev)
     ctx.upload(scene)
-    params = jp.render_params(W, H, spp_total, 5, 1234, band_rows=20, shard_index=rank, shard_count=n)
+    # bands that deal evenly over the ranks and over the two stream lanes inside each rank (16 rows for 512 rows, N <= 16)
+    band_rows = jp.distributed.balanced_band_rows(H, 2 * n)
+    lanes = 1 if os.environ.get("JETPBRT_LANES") == "1" else 2
+    lanes_note = ", %d stream lanes per GPU" % lanes
+    params = jp.render_params(W, H, spp_total, 5, 1234, band_rows=band_rows, shard_index=rank, shard_count=n)
     film_dev = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if world > 1 else None
 
     def step():
@@ -107,7 +113,9 @@ def main():
     fence()
     t0 = time.perf_counter()
     film = None
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == args.steps - 1:
+            ctx.set_profiling(True)                        # per-launch HIP events (kernel stream) on the last timed step: roofline below
         film = step()
     fence()
     dt = time.perf_counter() - t0
@@ -118,13 +126,8 @@ def main():
     samples_per_step = W * H * spp_total
     value = samples_per_step * args.steps / dt / 1e6
 
-    # ---- roofline of the dominant kernel class: one more step with per-launch HIP events on the kernel stream ----
-    ctx.set_profiling(True)
-    if world == 1:
-        ctx.render(params)
-    else:
-        ctx.render_device(params, film_dev.data_ptr(), sync=True)
-    c = ctx.counters()
+    # ---- roofline of the dominant kernel class: per-launch HIP events on the kernel stream, last timed step ----
+    c = ctx.counters()                                     # counters + per-class event times of the last timed step
     ctx.set_profiling(False)
     roof = None
     if rank == 0:
@@ -157,6 +160,9 @@ def main():
                 "unit_bytes": B_PER_SHADOW if dom == "k_shadow" else B_PER_SEGMENT, "units_per_launch": int((c.shadow_rays if dom == "k_shadow" else c.closest_rays) / launches),
                 "attributed_bytes_per_launch": int(attributed / launches),
                 "class_ms": {k: round(v[0], 3) for k, v in cls.items()},
+                # two stream lanes: the lanes' kernels overlap, so a launch's duration includes the time it shares the
+                # GPU with the other lane's kernel; kernel_time_over_wall is the average number of kernels in flight
+                "lanes": lanes, "kernel_time_over_wall": round((c.extend_ms + c.shade_ms + c.shadow_ms + c.other_ms) / max(1e-9, c.render_ms), 3),
                 "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "segments_per_sample": round(c.closest_rays / max(1, c.samples), 3),
                                "shadow_rays_per_sample": round(c.shadow_rays / max(1, c.samples), 3),
                                "achieved_GBps": round(value * 1e6 * bytes_per_sample / 1e9, 1),
@@ -209,7 +215,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cornell_box %dx%d, %d spp (%d per GPU share), %s, maxDepth 5, counter sampler seed 1234" % (
                 W, H, spp_total, args.spp, "full bsdf.cc + microfacet.cc materials" if args.full_materials else "Lambertian-only BSDF"),
-                "parallelism": "20-row band shard x%d + RCCL film reduce" % n if n > 1 else "single GPU"},
+                "parallelism": ("%d-row band shard x%d + RCCL film reduce" % (band_rows, n) if n > 1 else "single GPU") + lanes_note},
             "roofline": roof, "cpu_baseline": cpu, "l2_vs_cpu_ref": parity,
         }
         print(json.dumps(out), flush=True)

@@ -593,6 +593,7 @@ struct JpContext
 	std::vector<void*> qbufs;
 	float4* d_pix_acc = nullptr; size_t pix_acc_n = 0;
 	float* d_film = nullptr; size_t film_n = 0;
+	float* h_film = nullptr; size_t h_film_n = 0;                // pinned staging buffer of jp_render (a pageable copy of the film costs ~2 ms)
 	DevCounters* d_cnt = nullptr;
 	// timing
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -601,6 +602,12 @@ struct JpContext
 	struct Stamp { int cls; size_t a, b; };
 	std::vector<Stamp> stamps;
 	JpCounters counters;
+	// Second half-context ("lane"): the shard's bands are split in two and rendered concurrently on two streams with
+	// two queue sets, so the tail and the launch gap of one lane's kernel are filled by the other lane's (DESIGN.md
+	// section 5, "Two lanes").  The lane shares the scene tables (not owned) and writes its bands into its own film.
+	JpContext* lane = nullptr; bool is_lane = false; unsigned long long own_samples = 0;
+	float* d_lane_film = nullptr; size_t lane_film_n = 0;
+	hipEvent_t ev_lane_done = nullptr, ev_added = nullptr; bool added_valid = false, last_dual = false;
 };
 
 static void free_scene(JpContext* c)
@@ -647,9 +654,15 @@ int jp_destroy_context(JpContext* c)
 	if (!c) return JP_OK;
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
-	free_scene(c); free_queues(c);
+	if (c->lane) { JpContext* l = c->lane; c->lane = nullptr; std::memset(&l->sv, 0, sizeof(l->sv)); jp_destroy_context(l); }
+	if (c->d_lane_film) hipFree(c->d_lane_film);
+	if (c->ev_lane_done) hipEventDestroy(c->ev_lane_done);
+	if (c->ev_added) hipEventDestroy(c->ev_added);
+	if (!c->is_lane) free_scene(c);
+	free_queues(c);
 	if (c->d_pix_acc) hipFree(c->d_pix_acc);
 	if (c->d_film) hipFree(c->d_film);
+	if (c->h_film) hipHostFree(c->h_film);
 	if (c->d_cnt) hipFree(c->d_cnt);
 	for (hipEvent_t e : c->evpool) hipEventDestroy(e);
 	if (c->ev0) hipEventDestroy(c->ev0);
@@ -1085,7 +1098,7 @@ struct Stamper
 	~Stamper() { if (!c->profiling) return; hipEventRecord(c->evpool[a + 1], c->stream); JpContext::Stamp s = { cls, a, a + 1 }; c->stamps.push_back(s); }
 };
 
-int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sync)
+int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sync)
 {
 	if (!c || !rp || !film_dev) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: null argument");
 	if (!c->have_scene) return fail(JP_ERR_NO_SCENE, "jp_render: no scene uploaded");
@@ -1181,7 +1194,7 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 		HIP_TRY(hipGetLastError());
 	}
 	HIP_TRY(hipEventRecord(c->ev1, c->stream));
-	c->counters.samples = samples;
+	c->own_samples = samples;
 	if (sync)
 	{
 		HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1189,15 +1202,86 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 	return JP_OK;
 }
 
-int finish_counters(JpContext* c)
+// ---- two lanes: the shard's bands split in two, rendered concurrently on two streams -------------------------------------
+__global__ void __launch_bounds__(JP_BLOCK) k_add_film(float* __restrict__ dst, const float* __restrict__ src, size_t n)
 {
+	// the lanes' films are disjoint (zero outside a lane's bands), so the sum is the union, bit for bit
+	for (size_t i = (size_t)blockIdx.x * JP_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * JP_BLOCK) dst[i] += src[i];
+}
+
+int make_lane(JpContext* c)
+{
+	if (c->lane) return JP_OK;
+	JpContext* l = new JpContext;
+	l->device = c->device; l->is_lane = true; l->n_cus = c->n_cus; l->blocks_per_cu = c->blocks_per_cu;
+	std::memset(&l->counters, 0, sizeof(l->counters)); std::memset(&l->q, 0, sizeof(l->q));
+	if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&l->ev0) != hipSuccess || hipEventCreate(&l->ev1) != hipSuccess
+	    || hipMalloc((void**)&l->d_cnt, sizeof(DevCounters)) != hipSuccess
+	    || (!c->ev_lane_done && hipEventCreateWithFlags(&c->ev_lane_done, hipEventDisableTiming) != hipSuccess)
+	    || (!c->ev_added && hipEventCreateWithFlags(&c->ev_added, hipEventDisableTiming) != hipSuccess))
+	{ jp_destroy_context(l); return fail(JP_ERR_DEVICE, "jp_render: stream/event allocation for the second lane failed"); }
+	c->lane = l;
+	return JP_OK;
+}
+
+// the lane walks the same device tables as its parent (it owns none of them)
+void sync_lane_scene(JpContext* c)
+{
+	JpContext* l = c->lane; if (!l) return;
+	l->have_scene = c->have_scene; l->sv = c->sv; l->stack_depth = c->stack_depth; l->scene_in_lds = c->scene_in_lds;
+	l->lds_bytes = c->lds_bytes; l->lds_bytes_shadow = c->lds_bytes_shadow; l->trav_mode = c->trav_mode; l->n_planes = c->n_planes;
+	l->has_null_material = c->has_null_material; l->tables_in_lds = c->tables_in_lds; l->stage_nee = c->stage_nee; l->shade_lds_bytes = c->shade_lds_bytes;
+	l->profiling = c->profiling;
+}
+
+int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sync)
+{
+	if (!c || !rp || !film_dev) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: null argument");
+	c->last_dual = false;
+	bool dual = !c->is_lane && c->have_scene && !c->has_null_material && rp->width > 0 && rp->height > 0;
+	if (const char* e = getenv("JETPBRT_LANES")) { if (atoi(e) == 1) dual = false; }
+	const int band = rp->band_rows > 0 ? rp->band_rows : 20;
+	const int scount = rp->shard_count > 1 ? rp->shard_count : 1;
+	const int sidx = scount > 1 ? rp->shard_index : 0;
+	if (dual)
+	{   // both lanes need at least one band of this shard
+		const int nbands = (rp->height + band - 1) / band;
+		int mine = 0; for (int b = sidx; b < nbands; b += scount) mine++;
+		if (mine < 2 || sidx < 0 || sidx >= scount) dual = false;
+		// worth it only when each lane still gets full-size batches (2^24 slots): measured -7 % at 512 x 512 x 64 spp
+		// (half-size batches), +17 % at 1024 spp
+		long long rows = 0; for (int b = sidx; b < nbands; b += scount) rows += std::min(band, rp->height - b * band);
+		if (rows * rp->width * (long long)rp->spp < (2ll << 24) && !getenv("JETPBRT_LANES")) dual = false;
+	}
+	if (!dual) return render_one(c, rp, film_dev, sync);
+
 	HIP_TRY(hipSetDevice(c->device));
+	int st = make_lane(c); if (st != JP_OK) return st;
+	JpContext* l = c->lane;
+	sync_lane_scene(c);
+	const size_t n = (size_t)rp->width * rp->height * 3;
+	if (c->lane_film_n < n) { if (c->d_lane_film) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->d_lane_film); } c->d_lane_film = nullptr; c->added_valid = false; HIP_TRY(hipMalloc((void**)&c->d_lane_film, n * sizeof(float))); c->lane_film_n = n; }
+	// bands b with b % scount == sidx, alternately to the two lanes: lane k takes those with (b / scount) % 2 == k
+	JpRenderParams pa = *rp, pb = *rp;
+	pa.band_rows = pb.band_rows = band; pa.shard_count = pb.shard_count = 2 * scount; pa.shard_index = sidx; pb.shard_index = sidx + scount;
+	if (c->added_valid) HIP_TRY(hipStreamWaitEvent(l->stream, c->ev_added, 0));      // the previous frame's merge still reads the lane film
+	st = render_one(l, &pb, c->d_lane_film, false); if (st != JP_OK) return st;
+	st = render_one(c, &pa, film_dev, false); if (st != JP_OK) return st;
+	HIP_TRY(hipEventRecord(c->ev_lane_done, l->stream));
+	HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_lane_done, 0));
+	hipLaunchKernelGGL(k_add_film, dim3((unsigned int)std::min<size_t>((size_t)c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK)), dim3(JP_BLOCK), 0, c->stream, film_dev, (const float*)c->d_lane_film, n);
+	HIP_TRY(hipEventRecord(c->ev_added, c->stream)); c->added_valid = true;
+	HIP_TRY(hipEventRecord(c->ev1, c->stream));                                       // render_ms: both lanes and the merge
+	c->last_dual = true;
+	if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+	return JP_OK;
+}
+
+int finish_one(JpContext* c, JpCounters& o)
+{
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	DevCounters h; HIP_TRY(hipMemcpy(&h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost));
-	float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) ms = 0.f;
-	JpCounters& o = c->counters;
-	o.closest_rays = h.closest; o.closest_hits = h.closest_hit; o.shadow_rays = h.shadow; o.shadow_occluded = h.shadow_occ; o.render_ms = ms;
-	o.extend_ms = o.shade_ms = o.shadow_ms = o.other_ms = 0; o.extend_launches = o.shade_launches = o.shadow_launches = 0;
+	o.closest_rays += h.closest; o.closest_hits += h.closest_hit; o.shadow_rays += h.shadow; o.shadow_occluded += h.shadow_occ;
 	for (const JpContext::Stamp& s : c->stamps)
 	{
 		float t = 0.f; if (hipEventElapsedTime(&t, c->evpool[s.a], c->evpool[s.b]) != hipSuccess) continue;
@@ -1206,6 +1290,19 @@ int finish_counters(JpContext* c)
 		else if (s.cls == CLS_SHADOW) { o.shadow_ms += t; o.shadow_launches++; }
 		else o.other_ms += t;
 	}
+	return JP_OK;
+}
+
+int finish_counters(JpContext* c)
+{
+	HIP_TRY(hipSetDevice(c->device));
+	JpCounters& o = c->counters;
+	const unsigned long long samples = c->own_samples + ((c->last_dual && c->lane) ? c->lane->own_samples : 0ull);
+	std::memset(&o, 0, sizeof(o));
+	int st = finish_one(c, o); if (st != JP_OK) return st;
+	if (c->last_dual && c->lane) { st = finish_one(c->lane, o); if (st != JP_OK) return st; }      // per-class times add up over both (overlapping) lanes
+	float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) ms = 0.f;
+	o.render_ms = ms; o.samples = samples;
 	return JP_OK;
 }
 }
@@ -1221,9 +1318,12 @@ int jp_render(JpContext* c, const JpRenderParams* rp, float* film_host)
 	HIP_TRY(hipSetDevice(c->device));
 	size_t n = (size_t)rp->width * rp->height * 3;
 	if (c->film_n < n) { if (c->d_film) hipFree(c->d_film); c->d_film = nullptr; HIP_TRY(hipMalloc((void**)&c->d_film, n * sizeof(float))); c->film_n = n; }
+	if (c->h_film_n < n) { if (c->h_film) hipHostFree(c->h_film); c->h_film = nullptr; c->h_film_n = 0; if (hipHostMalloc((void**)&c->h_film, n * sizeof(float), hipHostMallocDefault) == hipSuccess) c->h_film_n = n; else c->h_film = nullptr; }
 	int st = render_impl(c, rp, c->d_film, false); if (st != JP_OK) return st;
-	HIP_TRY(hipMemcpyAsync(film_host, c->d_film, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	float* stage = c->h_film ? c->h_film : film_host;
+	HIP_TRY(hipMemcpyAsync(stage, c->d_film, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (stage != film_host) std::memcpy(film_host, stage, n * sizeof(float));
 	return JP_OK;
 }
 

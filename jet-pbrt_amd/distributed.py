@@ -14,6 +14,17 @@ def shard_params(width, height, spp, rank, world, max_depth=5, seed=1234, band_r
     return render_params(width, height, spp, max_depth, seed, band_rows=band_rows, shard_index=rank, shard_count=world)
 
 
+def balanced_band_rows(height, world, max_rows=20):
+    """Largest band height <= max_rows (the reference's lines_per_task, integrator.cc:53) that deals the film evenly:
+    it divides `height` and gives a band count that is a multiple of `world`.  With the counter sampler the film does
+    not depend on the band height, only the load balance does (512 rows on 8 ranks: 26 bands of 20 rows would give
+    two ranks 4 bands and six ranks 3; 32 bands of 16 rows give every rank 4).  Falls back to max_rows."""
+    for b in range(max_rows, 0, -1):
+        if height % b == 0 and (height // b) % world == 0:
+            return b
+    return max_rows
+
+
 def bands_of(height, rank, world, band_rows=20):
     nb = (height + band_rows - 1) // band_rows
     return [(b * band_rows, min(height, (b + 1) * band_rows)) for b in range(nb) if b % world == rank]

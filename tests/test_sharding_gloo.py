@@ -54,3 +54,14 @@ def test_band_assignment(H):
     assert b0 == [(0, 20), (60, 70)] and b1 == [(20, 40)] and b2 == [(40, 60)]
     rows = sorted(y for bs in (b0, b1, b2) for (a, b) in bs for y in range(a, b))
     assert rows == list(range(70))
+
+
+def test_balanced_band_rows_deals_evenly(H):
+    """N > 1 bench runs use the largest band height <= 20 that gives every rank the same number of rows"""
+    D = H.jp.distributed
+    assert D.balanced_band_rows(512, 1) == 16 and D.balanced_band_rows(512, 8) == 16 and D.balanced_band_rows(600, 4) == 15
+    assert D.balanced_band_rows(7, 3) == 20                       # nothing divides: the reference's 20
+    for height, world in ((512, 2), (512, 4), (512, 8), (600, 8), (1024, 8)):
+        b = D.balanced_band_rows(height, world)
+        rows = [sum(y1 - y0 for y0, y1 in D.bands_of(height, r, world, b)) for r in range(world)]
+        assert len(set(rows)) == 1 and sum(rows) == height and b <= 20
