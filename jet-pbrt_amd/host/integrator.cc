@@ -69,6 +69,17 @@ void FGpuPathIntegrator::Render(const FScene* scene, FSampler* sampler, FFilm* f
 		FlatScene flat; std::string err;
 		if (!FlattenScene(*scene, flat, &err)) { fprintf(stderr, "FGpuPathIntegrator::Render: %s\n", err.c_str()); lastStatus = JP_ERR_INVALID_ARGUMENT; return; }
 		lastStatus = api.upload_scene(ctx, &flat.view);
+		if (lastStatus == JP_ERR_UNSUPPORTED && flat.view.n_bvh_nodes == 0)
+		{   // FScene::deviceBuild, but the device-built tree was refused (deeper than the traversal stack): build the SAH tree
+			// on the host for this upload -- a different hierarchy, the same GPU path
+			fprintf(stderr, "FGpuPathIntegrator::Render: %s; building the hierarchy on the host instead\n", api.last_error());
+			std::vector<FBounds3> pb; pb.reserve(scene->primitives.size());
+			for (auto& p : scene->primitives) pb.push_back(p->shape->tightBox);
+			BuildBVH(pb, flat.bvh, 4);
+			flat.view.n_bvh_nodes = (int)flat.bvh.left.size(); flat.view.bvh_bounds = flat.bvh.bounds.data(); flat.view.bvh_left = flat.bvh.left.data(); flat.view.bvh_right = flat.bvh.right.data();
+			flat.view.n_bvh_prim_indices = (int)flat.bvh.prim_index.size(); flat.view.bvh_prim_index = flat.bvh.prim_index.data();
+			lastStatus = api.upload_scene(ctx, &flat.view);
+		}
 		if (lastStatus != JP_OK) { fprintf(stderr, "FGpuPathIntegrator::Render: %s\n", api.last_error()); return; }
 		uploaded = scene;
 	}
