@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU share (total spp = spp * gpus)")
     ap.add_argument("--full-materials", action="store_true", help="configs[2]: metal tall box instead of Lambertian-only")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")
+    ap.add_argument("--band-rows", type=int, default=0, help="band height for sharding / lanes (0: largest height <= 20 that deals evenly)")
     ap.add_argument("--cpu-bands", type=int, default=2, help="20-row bands rendered by the CPU oracle at the full spp (parity sample)")
     args = ap.parse_args()
 
@@ -84,8 +85,8 @@ def main():
     ctx = jp.Context(dev)
     ctx.upload(scene)
     # bands that deal evenly over the ranks and over the two stream lanes inside each rank (16 rows for 512 rows, N <= 16)
-    band_rows = jp.distributed.balanced_band_rows(H, 2 * n)
-    lanes = 1 if os.environ.get("JETPBRT_LANES") == "1" else 2
+    lanes = int(os.environ.get("JETPBRT_LANES", "2"))
+    band_rows = args.band_rows if args.band_rows > 0 else jp.distributed.balanced_band_rows(H, lanes * n)
     lanes_note = ", %d stream lanes per GPU" % lanes
     params = jp.render_params(W, H, spp_total, 5, 1234, band_rows=band_rows, shard_index=rank, shard_count=n)
     film_dev = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if world > 1 else None

@@ -602,12 +602,12 @@ struct JpContext
 	struct Stamp { int cls; size_t a, b; };
 	std::vector<Stamp> stamps;
 	JpCounters counters;
-	// Second half-context ("lane"): the shard's bands are split in two and rendered concurrently on two streams with
-	// two queue sets, so the tail and the launch gap of one lane's kernel are filled by the other lane's (DESIGN.md
-	// section 5, "Two lanes").  The lane shares the scene tables (not owned) and writes its bands into its own film.
-	JpContext* lane = nullptr; bool is_lane = false; unsigned long long own_samples = 0; bool bpc_from_env = false;
-	float* d_lane_film = nullptr; size_t lane_film_n = 0;
-	hipEvent_t ev_lane_done = nullptr, ev_added = nullptr; bool added_valid = false, last_dual = false;
+	// Extra "lanes": the shard's bands are dealt round-robin to L lanes (this context + L - 1 lane contexts) and rendered
+	// concurrently on L streams with L queue sets, so the tail and the launch gap of one lane's kernel are filled by another
+	// lane's and bandwidth-bound kernels overlap instruction-bound ones ("Stream lanes").  A lane shares
+	// the scene tables (not owned) and writes its bands into its own film; the films are merged at the end.
+	std::vector<JpContext*> lanes; bool is_lane = false; unsigned long long own_samples = 0; bool bpc_from_env = false;
+	hipEvent_t ev_added = nullptr; bool added_valid = false; int last_lanes = 1;      // lanes used by the last render (1: this context alone)
 };
 
 static void free_scene(JpContext* c)
@@ -654,9 +654,8 @@ int jp_destroy_context(JpContext* c)
 	if (!c) return JP_OK;
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
-	if (c->lane) { JpContext* l = c->lane; c->lane = nullptr; std::memset(&l->sv, 0, sizeof(l->sv)); jp_destroy_context(l); }
-	if (c->d_lane_film) hipFree(c->d_lane_film);
-	if (c->ev_lane_done) hipEventDestroy(c->ev_lane_done);
+	for (JpContext* l : c->lanes) { std::memset(&l->sv, 0, sizeof(l->sv)); jp_destroy_context(l); }
+	c->lanes.clear();
 	if (c->ev_added) hipEventDestroy(c->ev_added);
 	if (!c->is_lane) free_scene(c);
 	free_queues(c);
@@ -1202,32 +1201,32 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 	return JP_OK;
 }
 
-// ---- two lanes: the shard's bands split in two, rendered concurrently on two streams -------------------------------------
+// ---- stream lanes: the shard's bands dealt to L lanes, rendered concurrently on L streams with L queue sets ---------------
 __global__ void __launch_bounds__(JP_BLOCK) k_add_film(float* __restrict__ dst, const float* __restrict__ src, size_t n)
 {
 	// the lanes' films are disjoint (zero outside a lane's bands), so the sum is the union, bit for bit
 	for (size_t i = (size_t)blockIdx.x * JP_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * JP_BLOCK) dst[i] += src[i];
 }
 
-int make_lane(JpContext* c)
+int make_lanes(JpContext* c, int extra)
 {
-	if (c->lane) return JP_OK;
-	JpContext* l = new JpContext;
-	l->device = c->device; l->is_lane = true; l->n_cus = c->n_cus; l->blocks_per_cu = c->blocks_per_cu;
-	std::memset(&l->counters, 0, sizeof(l->counters)); std::memset(&l->q, 0, sizeof(l->q));
-	if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&l->ev0) != hipSuccess || hipEventCreate(&l->ev1) != hipSuccess
-	    || hipMalloc((void**)&l->d_cnt, sizeof(DevCounters)) != hipSuccess
-	    || (!c->ev_lane_done && hipEventCreateWithFlags(&c->ev_lane_done, hipEventDisableTiming) != hipSuccess)
-	    || (!c->ev_added && hipEventCreateWithFlags(&c->ev_added, hipEventDisableTiming) != hipSuccess))
-	{ jp_destroy_context(l); return fail(JP_ERR_DEVICE, "jp_render: stream/event allocation for the second lane failed"); }
-	c->lane = l;
+	if (!c->ev_added && hipEventCreateWithFlags(&c->ev_added, hipEventDisableTiming) != hipSuccess) return fail(JP_ERR_DEVICE, "jp_render: event allocation failed");
+	while ((int)c->lanes.size() < extra)
+	{
+		JpContext* l = new JpContext;
+		l->device = c->device; l->is_lane = true; l->n_cus = c->n_cus; l->blocks_per_cu = c->blocks_per_cu;
+		std::memset(&l->counters, 0, sizeof(l->counters)); std::memset(&l->q, 0, sizeof(l->q));
+		if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&l->ev0) != hipSuccess || hipEventCreate(&l->ev1) != hipSuccess
+		    || hipMalloc((void**)&l->d_cnt, sizeof(DevCounters)) != hipSuccess)
+		{ jp_destroy_context(l); return fail(JP_ERR_DEVICE, "jp_render: stream/event allocation for an extra lane failed"); }
+		c->lanes.push_back(l);
+	}
 	return JP_OK;
 }
 
-// the lane walks the same device tables as its parent (it owns none of them)
-void sync_lane_scene(JpContext* c)
+// a lane walks the same device tables as its parent (it owns none of them)
+void sync_lane_scene(JpContext* c, JpContext* l)
 {
-	JpContext* l = c->lane; if (!l) return;
 	l->have_scene = c->have_scene; l->sv = c->sv; l->stack_depth = c->stack_depth; l->scene_in_lds = c->scene_in_lds;
 	l->lds_bytes = c->lds_bytes; l->lds_bytes_shadow = c->lds_bytes_shadow; l->trav_mode = c->trav_mode; l->n_planes = c->n_planes;
 	l->has_null_material = c->has_null_material; l->tables_in_lds = c->tables_in_lds; l->stage_nee = c->stage_nee; l->shade_lds_bytes = c->shade_lds_bytes;
@@ -1237,48 +1236,59 @@ void sync_lane_scene(JpContext* c)
 int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sync)
 {
 	if (!c || !rp || !film_dev) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: null argument");
-	c->last_dual = false;
-	bool dual = !c->is_lane && c->have_scene && !c->has_null_material && rp->width > 0 && rp->height > 0;
-	if (const char* e = getenv("JETPBRT_LANES")) { if (atoi(e) == 1) dual = false; }
+	c->last_lanes = 1;
+	int L = 2;                                                   // lanes: 2 by default, JETPBRT_LANES = 1 .. 4
+	bool forced = false;
+	if (const char* e = getenv("JETPBRT_LANES")) { int v = atoi(e); if (v >= 1 && v <= 4) { L = v; forced = true; } }
+	if (c->is_lane || !c->have_scene || c->has_null_material || rp->width <= 0 || rp->height <= 0) L = 1;
 	const int band = rp->band_rows > 0 ? rp->band_rows : 20;
 	const int scount = rp->shard_count > 1 ? rp->shard_count : 1;
 	const int sidx = scount > 1 ? rp->shard_index : 0;
-	if (dual)
-	{   // both lanes need at least one band of this shard
-		const int nbands = (rp->height + band - 1) / band;
-		int mine = 0; for (int b = sidx; b < nbands; b += scount) mine++;
-		if (mine < 2 || sidx < 0 || sidx >= scount) dual = false;
-		// worth it only when each lane still gets full-size batches (2^24 slots): measured -7 % at 512 x 512 x 64 spp
-		// (half-size batches), +17 % at 1024 spp
-		long long rows = 0; for (int b = sidx; b < nbands; b += scount) rows += std::min(band, rp->height - b * band);
-		if (rows * rp->width * (long long)rp->spp < (2ll << 24) && !getenv("JETPBRT_LANES")) dual = false;
+	if (L > 1)
+	{
+		if (sidx < 0 || sidx >= scount) L = 1;
+		else
+		{
+			const int nbands = (rp->height + band - 1) / band;
+			int mine = 0; long long rows = 0;
+			for (int b = sidx; b < nbands; b += scount) { mine++; rows += std::min(band, rp->height - b * band); }
+			if (mine < L) L = mine < 1 ? 1 : mine;                // every lane needs at least one band of this shard
+			// worth it only when each lane still gets full-size batches (2^24 slots): measured -7 % at 512 x 512 x 64 spp
+			// (half-size batches), +17 % at 1024 spp
+			while (L > 1 && !forced && rows * rp->width * (long long)rp->spp < ((long long)L << 24)) L--;
+		}
 	}
-	if (!dual) return render_one(c, rp, film_dev, sync);
+	if (L <= 1) return render_one(c, rp, film_dev, sync);
 
 	HIP_TRY(hipSetDevice(c->device));
-	int st = make_lane(c); if (st != JP_OK) return st;
-	JpContext* l = c->lane;
-	sync_lane_scene(c);
+	int st = make_lanes(c, L - 1); if (st != JP_OK) return st;
 	const size_t n = (size_t)rp->width * rp->height * 3;
-	if (c->lane_film_n < n) { if (c->d_lane_film) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->d_lane_film); } c->d_lane_film = nullptr; c->added_valid = false; HIP_TRY(hipMalloc((void**)&c->d_lane_film, n * sizeof(float))); c->lane_film_n = n; }
-	// bands b with b % scount == sidx, alternately to the two lanes: lane k takes those with (b / scount) % 2 == k
-	JpRenderParams pa = *rp, pb = *rp;
-	pa.band_rows = pb.band_rows = band; pa.shard_count = pb.shard_count = 2 * scount; pa.shard_index = sidx; pb.shard_index = sidx + scount;
-	if (c->added_valid) HIP_TRY(hipStreamWaitEvent(l->stream, c->ev_added, 0));      // the previous frame's merge still reads the lane film
-	// workgroups per CU and lane: 8 + 8 (measured on the benchmark frame: 2.51 Gsamples/s at 16 + 16, 2.70 at 8 + 8, 2.74 at
-	// 6 + 6, 2.60 at 4 + 4; a single lane is best at 16)
-	const int bpc_single = c->blocks_per_cu, bpc_dual = c->bpc_from_env ? c->blocks_per_cu : 8;
-	c->blocks_per_cu = l->blocks_per_cu = bpc_dual;
-	st = render_one(l, &pb, c->d_lane_film, false);
-	if (st == JP_OK) st = render_one(c, &pa, film_dev, false);
-	c->blocks_per_cu = bpc_single;
+	// workgroups per CU and lane (measured on the benchmark frame, two lanes: 2.51 Gsamples/s at 16 + 16, 2.70 at 8 + 8,
+	// 2.74 at 6 + 6, 2.60 at 4 + 4; three lanes: 2.87 at 4 + 4 + 4; a single lane is best at 16)
+	const int bpc_single = c->blocks_per_cu, bpc_lane = c->bpc_from_env ? c->blocks_per_cu : std::max(4, 16 / L);
+	// bands b with b % scount == sidx go round-robin to the lanes: lane k takes those with (b / scount) % L == k
+	JpRenderParams pk = *rp; pk.band_rows = band; pk.shard_count = L * scount;
+	for (int k = 1; k < L && st == JP_OK; k++)
+	{
+		JpContext* l = c->lanes[k - 1];
+		sync_lane_scene(c, l);
+		if (l->film_n < n) { if (l->d_film) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(l->d_film); } l->d_film = nullptr; l->film_n = 0; HIP_TRY(hipMalloc((void**)&l->d_film, n * sizeof(float))); l->film_n = n; c->added_valid = false; }
+		if (c->added_valid) HIP_TRY(hipStreamWaitEvent(l->stream, c->ev_added, 0));   // the previous frame's merge still reads the lane film
+		l->blocks_per_cu = bpc_lane;
+		pk.shard_index = sidx + k * scount;
+		st = render_one(l, &pk, l->d_film, false);
+	}
+	if (st == JP_OK) { c->blocks_per_cu = bpc_lane; pk.shard_index = sidx; st = render_one(c, &pk, film_dev, false); c->blocks_per_cu = bpc_single; }
 	if (st != JP_OK) return st;
-	HIP_TRY(hipEventRecord(c->ev_lane_done, l->stream));
-	HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_lane_done, 0));
-	hipLaunchKernelGGL(k_add_film, dim3((unsigned int)std::min<size_t>((size_t)c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK)), dim3(JP_BLOCK), 0, c->stream, film_dev, (const float*)c->d_lane_film, n);
+	for (int k = 1; k < L; k++)
+	{
+		JpContext* l = c->lanes[k - 1];
+		HIP_TRY(hipStreamWaitEvent(c->stream, l->ev1, 0));                           // recorded at the end of the lane's render_one
+		hipLaunchKernelGGL(k_add_film, dim3((unsigned int)std::min<size_t>((size_t)c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK)), dim3(JP_BLOCK), 0, c->stream, film_dev, (const float*)l->d_film, n);
+	}
 	HIP_TRY(hipEventRecord(c->ev_added, c->stream)); c->added_valid = true;
-	HIP_TRY(hipEventRecord(c->ev1, c->stream));                                       // render_ms: both lanes and the merge
-	c->last_dual = true;
+	HIP_TRY(hipEventRecord(c->ev1, c->stream));                                       // render_ms: all lanes and the merge
+	c->last_lanes = L;
 	if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
 	return JP_OK;
 }
@@ -1303,10 +1313,11 @@ int finish_counters(JpContext* c)
 {
 	HIP_TRY(hipSetDevice(c->device));
 	JpCounters& o = c->counters;
-	const unsigned long long samples = c->own_samples + ((c->last_dual && c->lane) ? c->lane->own_samples : 0ull);
+	unsigned long long samples = c->own_samples;
 	std::memset(&o, 0, sizeof(o));
 	int st = finish_one(c, o); if (st != JP_OK) return st;
-	if (c->last_dual && c->lane) { st = finish_one(c->lane, o); if (st != JP_OK) return st; }      // per-class times add up over both (overlapping) lanes
+	for (int k = 1; k < c->last_lanes; k++)                                           // per-class times add up over the (overlapping) lanes
+	{ samples += c->lanes[k - 1]->own_samples; st = finish_one(c->lanes[k - 1], o); if (st != JP_OK) return st; }
 	float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) ms = 0.f;
 	o.render_ms = ms; o.samples = samples;
 	return JP_OK;
