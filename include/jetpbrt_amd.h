@@ -126,6 +126,10 @@ typedef struct JpBuildInfo {
     int32_t traversal_mode;      /* 0 binary tree in HBM, 1 binary tree in LDS, 2 flat leaf list, 3 binary + 8-wide */
     int32_t bvh_nodes, bvh_height;
     double  device_build_ms;     /* HIP-event time of the device build (0 when the caller's tree was used)     */
+    int32_t libm_sincosf;        /* which build of the host libm's sinf/cosf/sincosf the device reproduces bit for bit:
+                                    1 = glibc's FMA build, 2 = its build without contraction, 0 = none (own correctly
+                                    rounded evaluation; films then differ from the host reference by rare path flips)  */
+    int32_t reserved;
 } JpBuildInfo;
 
 typedef struct JpContext JpContext;

@@ -60,7 +60,7 @@ class JpCounters(C.Structure):
 
 class JpBuildInfo(C.Structure):
     _fields_ = [("built_on_device", C.c_int32), ("traversal_mode", C.c_int32), ("bvh_nodes", C.c_int32), ("bvh_height", C.c_int32),
-                ("device_build_ms", C.c_double)]
+                ("device_build_ms", C.c_double), ("libm_sincosf", C.c_int32), ("reserved", C.c_int32)]
 
 
 def render_params(width, height, spp, max_depth=5, seed=1234, sampler_mode=JP_SAMPLER_COUNTER,

@@ -585,7 +585,7 @@ struct JpContext
 	SceneView sv; int stack_depth = 1; bool scene_in_lds = false; size_t lds_bytes = 0, lds_bytes_shadow = 0;
 	void *d_flat = nullptr, *d_flat_leaf = nullptr, *d_wide = nullptr; int trav_mode = 0;
 	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr;
-	int n_planes = 1; bool has_null_material = false;
+	int n_planes = 1; bool has_null_material = false; int sincosf_mode = 0;
 	bool build_on_device = false; float build_ms = 0.f; int bvh_height = 0, bvh_nodes = 0;
 	bool tables_in_lds = false, stage_nee = false; size_t shade_lds_bytes = 0;
 	// queues
@@ -622,6 +622,39 @@ static void free_queues(JpContext* c)
 	c->qbufs.clear(); c->cap = 0; c->planes_alloc = 0;
 }
 
+// Which build of glibc's sinf / cosf / sincosf does this host run (jp_shading.h, sincosf_libm)?  The reference computes its
+// bounce directions with them, so the device reproduces whichever the host's IFUNC resolver picked: 1 = the FMA build,
+// 2 = the build without contraction, 0 = neither reproduces the host on the probe set (another libm): the device then
+// keeps its own correctly rounded evaluation.
+static int probe_host_sincosf()
+{
+	static int cached = -1;
+	if (cached >= 0) return cached;
+	bool okF = true, okN = true;
+	uint32_t st = 0x12345u;
+	for (int i = 0; i < 200000 && (okF || okN); i++)
+	{
+		st = st * 1664525u + 1013904223u;
+		float y;
+		if (i < 150000) y = (float)(st >> 8) * (1.0f / 16777216.0f) * 6.2831855f;      // the call sites' range [0, 2 pi)
+		else if (i < 180000) y = (float)(st >> 8) * (1.0f / 16777216.0f) * 0.01f;       // small arguments, incl. the < 2^-12 branch
+		else y = ((float)(st >> 8) * (1.0f / 16777216.0f) - 0.5f) * 200.f;               // both signs, up to |y| = 100
+		float hs, hc; ::sincosf(y, &hs, &hc);
+		const float h1 = ::sinf(y), h2 = ::cosf(y);
+		float as, ac, bs, bc;
+		jp::sincosf_libm<true>(y, &as, &ac); jp::sincosf_libm<false>(y, &bs, &bc);
+		uint32_t uhs, uhc, u1, u2, uas, uac, ubs, ubc;
+		std::memcpy(&uhs, &hs, 4); std::memcpy(&uhc, &hc, 4); std::memcpy(&u1, &h1, 4); std::memcpy(&u2, &h2, 4);
+		std::memcpy(&uas, &as, 4); std::memcpy(&uac, &ac, 4); std::memcpy(&ubs, &bs, 4); std::memcpy(&ubc, &bc, 4);
+		if (uhs != u1 || uhc != u2) { okF = okN = false; }                             // sinf / cosf / sincosf must agree with each other
+		if (uas != uhs || uac != uhc) okF = false;
+		if (ubs != uhs || ubc != uhc) okN = false;
+	}
+	cached = okF ? 1 : (okN ? 2 : 0);
+	if (const char* e = getenv("JETPBRT_SINCOSF")) { int v = atoi(e); if (v >= 0 && v <= 2) cached = v; }
+	return cached;
+}
+
 extern "C" {
 
 const char* jp_last_error(void) { return g_err.c_str(); }
@@ -645,6 +678,8 @@ int jp_create_context(int device_id, JpContext** out)
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess
 	    || hipMalloc((void**)&c->d_cnt, sizeof(DevCounters)) != hipSuccess)
 	{ delete c; return fail(JP_ERR_DEVICE, "jp_create_context: stream/event/counter allocation failed"); }
+	c->sincosf_mode = probe_host_sincosf();
+	{ hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(jp::g_sincosf_mode), &c->sincosf_mode, sizeof(int)); if (e != hipSuccess) { jp_destroy_context(c); return fail(JP_ERR_DEVICE, std::string("jp_create_context: hipMemcpyToSymbol: ") + hipGetErrorString(e)); } }
 	*out = c;
 	return JP_OK;
 }
@@ -1357,7 +1392,7 @@ int jp_get_build_info(JpContext* c, JpBuildInfo* out)
 	if (!c || !out) return fail(JP_ERR_INVALID_ARGUMENT, "jp_get_build_info: null argument");
 	if (!c->have_scene) return fail(JP_ERR_NO_SCENE, "jp_get_build_info: no scene uploaded");
 	out->built_on_device = c->build_on_device ? 1 : 0; out->traversal_mode = c->trav_mode; out->bvh_nodes = c->bvh_nodes; out->bvh_height = c->bvh_height;
-	out->device_build_ms = c->build_ms;
+	out->device_build_ms = c->build_ms; out->libm_sincosf = c->sincosf_mode;
 	return JP_OK;
 }
 

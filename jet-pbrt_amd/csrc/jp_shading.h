@@ -8,6 +8,7 @@
 // value in all but ~1e-9 of cases, which coincides with glibc's result wherever glibc is correctly rounded.
 #pragma once
 #include "jp_device.h"
+#define JP_HD_INLINE __host__ __device__ __forceinline__
 
 namespace jp
 {
@@ -43,7 +44,69 @@ __device__ __forceinline__ void sincos_d(float xf, double* s, double* c)
 	*s = (k & 2) ? -ss : ss;
 	*c = ((k + 1) & 2) ? -cc : cc;
 }
-__device__ __forceinline__ void sincos_f(float xf, float* s, float* c) { double sd, cd; sincos_d(xf, &sd, &cd); *s = (float)sd; *c = (float)cd; }
+
+// ---- sinf / cosf / sincosf exactly as the host's libm computes them ---------------------------------------------------
+// glibc >= 2.28 evaluates the three functions with one algorithm (sysdeps/ieee754/flt-32/s_sincosf.h, from the Arm
+// optimized routines): the argument is widened to fp64, reduced by n * pi/2 with n = ((int)(x * 2^24 * 2/pi) + 2^23) >> 24,
+// and two fixed fp64 polynomials are evaluated; the fp64 results are rounded once to fp32.  Every step is IEEE fp64
+// arithmetic, so the device can reproduce the host's fp32 results BIT FOR BIT -- which removes the last source of
+// difference between the device film and the reference's (a 1-ulp different bounce direction is harmless in the Cornell
+// box but flips whole paths on finely tessellated, flat-shaded meshes).  Two builds of that code exist in libm and an
+// IFUNC picks one per CPU: compiled with FMA contraction (x86-64 with FMA + AVX2) or without.  kFma selects which one is
+// reproduced; jp_create_context probes the host's sincosf and sets g_sincosf_mode (0: neither matches, keep sincos_d).
+// Transcribed from the polynomial data flow of the compiled routines: sin = (s2 + x2 s3) * (x2 x3) + (xs + x3 s1),
+// cos = (c3 + x2 c4) * (x2 x4) + ((c0 + x2 c1) + x4 c2), x3 = x2 xs, x4 = x2 x2, each "a * b + c" one fma when kFma.
+__device__ __constant__ int g_sincosf_mode = 0;
+
+template <bool kFma>
+JP_HD_INLINE void sincosf_libm(float y, float* sp, float* cp)
+{
+	union { float f; unsigned int u; } bits; bits.f = y;
+	const unsigned int top = (bits.u >> 20) & 0x7ffu;                      // abstop12
+	const double x = (double)y;
+	double xs, x2; int n = 0;
+	if (top <= 0x3f3u)                                                     // |y| < pi/4
+	{
+		if (top <= 0x397u) { *sp = y; *cp = 1.0f; return; }                // |y| < 2^-12
+		xs = x; x2 = x * x;
+	}
+	else
+	{   // pi/4 <= |y| < 120 on every call site (angles in [0, 2 pi]); reduce_fast
+		const double r = x * 0x1.45f306dc9c883p+23;
+		n = ((int)r + 0x800000) >> 24;
+		const double xr = kFma ? fma(-(double)n, 0x1.921fb54442d18p+0, x) : x - (double)n * 0x1.921fb54442d18p+0;
+		const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;    // sign of sine in quadrants 0..3
+		xs = xr * sgn; x2 = xr * xr;
+	}
+	const double t = (n & 2) ? -1.0 : 1.0;                                 // second table: cosine coefficients negated
+	const double c0 = t, c1 = t * -0x1.ffffffd0c621cp-2, c2 = t * 0x1.55553e1068f19p-5, c3 = t * -0x1.6c087e89a359dp-10, c4 = t * 0x1.99343027bf8c3p-16;
+	const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+	const double x3 = x2 * xs, x4 = x2 * x2;
+	const double x5 = x2 * x3, x6 = x2 * x4;
+	double c1v, as, ac, bs, bc, S, C;
+	if (kFma)
+	{
+		c1v = fma(x2, c1, c0); as = fma(x2, s3, s2); ac = fma(x2, c4, c3);
+		bs = fma(x3, s1, xs); bc = fma(x4, c2, c1v);
+		S = fma(as, x5, bs); C = fma(ac, x6, bc);
+	}
+	else
+	{
+		c1v = c0 + x2 * c1; as = s2 + x2 * s3; ac = c3 + x2 * c4;
+		bs = xs + x3 * s1; bc = c1v + x4 * c2;
+		S = bs + x5 * as; C = bc + x6 * ac;
+	}
+	const float fs = (float)S, fc = (float)C;
+	if (n & 1) { *sp = fc; *cp = fs; } else { *sp = fs; *cp = fc; }
+}
+
+__device__ __forceinline__ void sincos_f(float xf, float* s, float* c)
+{
+	const int mode = g_sincosf_mode;                                       // uniform: one scalar load
+	if (mode == 1 && fabsf(xf) < 120.f) sincosf_libm<true>(xf, s, c);
+	else if (mode == 2 && fabsf(xf) < 120.f) sincosf_libm<false>(xf, s, c);
+	else { double sd, cd; sincos_d(xf, &sd, &cd); *s = (float)sd; *c = (float)cd; }
+}
 
 #define JP_2PI      (2.0f * JP_PI)
 #define JP_PI_OVER2 (JP_PI / 2.0f)

@@ -2,10 +2,13 @@
 inputs, against the committed golden films of the reference, and through size-independent properties at the
 benchmark size.
 
-Tolerances.  Hit records (t, primitive, normal) are integer/IEEE-exact work: BIT-EXACT.  Films: the device
-evaluates sin/cos in fp64 rounded to fp32 whereas the reference calls glibc sinf/cosf (~0.56 ulp, not correctly
-rounded), so a last-bit difference in a sampled direction can, rarely, flip a discrete decision of one path.
-Gate (BASELINE.json north_star): mean over pixels of the per-pixel RGB L2 distance < 1e-4; observed 1e-10..2e-5.
+Tolerances.  Hit records (t, primitive, normal) are integer/IEEE-exact work: BIT-EXACT.  Films: every operation of the
+path is restated exactly, and the device reproduces the host libm's sinf / cosf / sincosf bit for bit when it recognises
+it (glibc >= 2.28: JpBuildInfo.libm_sincosf != 0), so on scenes whose geometry the reference's own BVH never drops a hit
+on (everything here but the tessellated bunny meshes) the film is BIT-IDENTICAL to the oracle's, ray counts included --
+asserted below through `assert_film(...)`.  Otherwise (another libm; or the bunny meshes, where the reference's box test
+`tmax <= tmin` rejects ~3e-4 of the true nearest hits depending on its rand()-driven topology, DESIGN.md "Numerics") the
+gate of BASELINE.json's north_star applies: mean over pixels of the per-pixel RGB L2 distance < 1e-4.
 """
 import ctypes as C
 import os
@@ -20,6 +23,17 @@ SCENE_NAMES = ["cornell", "cornell_lambert", "bunny_small", "misc", "lights"]
 
 def l2(a, b):
     return float(np.sqrt(((a - b) ** 2).sum(-1)).mean())
+
+
+EXACT_SCENES = ("cornell", "cornell_lambert", "misc", "lights")   # no tessellated mesh: the reference's BVH drops no hit
+
+
+def assert_film(gpu_ctx, film, ref, name=None, tol=TOL_L2):
+    """bit-identical when the device reproduces the host libm (and the scene has no reference-BVH misses), else the L2 gate"""
+    if gpu_ctx.build_info().libm_sincosf != 0 and (name is None or name in EXACT_SCENES):
+        assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)), "film differs from the oracle: mean L2 %.3e, exact px %.5f" % (l2(film, ref), (film == ref).all(-1).mean())
+    else:
+        assert l2(film, ref) < tol, l2(film, ref)
 
 
 def _scene(H, name, W, Hh):
@@ -80,8 +94,12 @@ def test_film_vs_golden_reference_and_oracle(H, gpu_ctx, name):
     gold = np.load(os.path.join(H.GOLDEN, "film_%s_counter.npy" % name))
     assert np.isfinite(film).all()
     assert l2(film, gold) < TOL_L2, l2(film, gold)
-    assert (film == gold).all(-1).mean() > 0.8                  # most pixels are bit-identical
+    assert (film == gold).all(-1).mean() > 0.8                  # most pixels are bit-identical (all of them on the host the goldens were made on)
+    ref, ocnt = H.oracle_render(sp, p, 4)
+    assert_film(gpu_ctx, film, ref, name)
     c = gpu_ctx.counters()
+    if gpu_ctx.build_info().libm_sincosf != 0 and name in EXACT_SCENES:
+        assert (c.closest_rays, c.closest_hits, c.shadow_rays, c.shadow_occluded) == (ocnt.closest_rays, ocnt.closest_hits, ocnt.shadow_rays, ocnt.shadow_occluded)
     import json
     counts = json.load(open(os.path.join(H.GOLDEN, "counts.json")))[name + "_counter"]
     got = [c.closest_rays, c.closest_hits, c.shadow_rays, c.shadow_occluded]
@@ -102,7 +120,7 @@ def test_film_vs_oracle_more_configs(H, gpu_ctx, name, W, Hh, spp, depth, seed):
     p = H.jp.render_params(W, Hh, spp, depth, seed)
     film = gpu_ctx.render(p)
     ref, cnt = H.oracle_render(sp, p, 8)
-    assert l2(film, ref) < TOL_L2, l2(film, ref)
+    assert_film(gpu_ctx, film, ref, name)
     assert np.abs(film - ref).max() < 0.25
     c = gpu_ctx.counters()
     assert abs(c.closest_rays - cnt.closest_rays) <= max(8, cnt.closest_rays * 2e-4)
@@ -119,7 +137,8 @@ def test_edge_cases(H, gpu_ctx):
         p = H.jp.render_params(W, Hh, spp, depth, 11)
         film = gpu_ctx.render(p)
         ref, _ = H.oracle_render(sp, p, 2)
-        assert film.shape == (Hh, W, 3) and l2(film, ref) < TOL_L2
+        assert film.shape == (Hh, W, 3)
+        assert_film(gpu_ctx, film, ref, "cornell")
     # determinism: two renders are bit-identical (no float atomics on the radiance path)
     hb, sp = _scene(H, "misc", 64, 64)
     gpu_ctx.upload(sp)
@@ -213,6 +232,7 @@ def test_benchmark_size_properties(H, gpu_ctx):
         ref, _ = H.oracle_render(sp, p, len(os.sched_getaffinity(0)))
         d = np.sqrt(((film[b * 20:b * 20 + 20] - ref[b * 20:b * 20 + 20]) ** 2).sum(-1))
         tot += d.sum(); npx += d.size
+        assert_film(gpu_ctx, film[b * 20:b * 20 + 20], ref[b * 20:b * 20 + 20], "cornell_lambert")
     assert tot / npx < TOL_L2, tot / npx
     # linearity in spp: independent halves of the sample set average to the whole (sequential fp32 sums differ by rounding only)
     a = gpu_ctx.render(H.jp.render_params(W, Hh, 64))
@@ -250,7 +270,7 @@ def test_random_scenes(H, gpu_ctx, tmp_path, seed):
     film = gpu_ctx.render(p)
     ref, cnt = H.oracle_render(sp, p, 8)
     assert np.isfinite(film).all()
-    assert l2(film, ref) < TOL_L2, l2(film, ref)
+    assert_film(gpu_ctx, film, ref)                              # 400-triangle soups: no reference-BVH misses observed
     c = gpu_ctx.counters()
     assert abs(c.closest_rays - cnt.closest_rays) <= max(8, cnt.closest_rays * 5e-4)
     rng = np.random.default_rng(seed)
@@ -487,3 +507,57 @@ def test_two_lanes_render_the_same_film_as_one(H, gpu_ctx, monkeypatch):
     ref, _ = H.oracle_render(sp, H.jp.render_params(96, 100, 16, 5, 21), 4)
     assert l2(gpu_ctx.render(H.jp.render_params(96, 100, 16, 5, 21)), ref) < TOL_L2
     monkeypatch.delenv("JETPBRT_LANES")
+
+
+def test_full_material_benchmark_size(H, gpu_ctx):
+    """BASELINE.json configs[2] (512x512x1024 spp, full bsdf.cc + microfacet.cc materials): full-spp parity on two whole
+    bands against the oracle, ray statistics, clamping; runs on two stream lanes like the bench"""
+    W = Hh = 512; spp = 1024
+    hb, sp = _scene(H, "cornell", W, Hh)
+    gpu_ctx.upload(sp)
+    film = gpu_ctx.render(H.jp.render_params(W, Hh, spp))
+    c = gpu_ctx.counters()
+    assert c.samples == W * Hh * spp and np.isfinite(film).all() and film.min() >= 0 and film.max() <= 1
+    nb = (Hh + 19) // 20
+    tot = 0.0; npx = 0; ocnt = [0, 0, 0]
+    for b in (9, 21):                                            # the band through the tall (plastic) box and one through the metal box
+        p = H.jp.render_params(W, Hh, spp, shard_index=b, shard_count=nb)
+        ref, cnt = H.oracle_render(sp, p, len(os.sched_getaffinity(0)))
+        d = np.sqrt(((film[b * 20:b * 20 + 20] - ref[b * 20:b * 20 + 20]) ** 2).sum(-1))
+        tot += d.sum(); npx += d.size
+        assert_film(gpu_ctx, film[b * 20:b * 20 + 20], ref[b * 20:b * 20 + 20], "cornell")
+        part = gpu_ctx.render(p); pc = gpu_ctx.counters()         # the same band alone: identical pixels, near-identical ray counts
+        assert np.array_equal(part[b * 20:b * 20 + 20].view(np.uint32), film[b * 20:b * 20 + 20].view(np.uint32))
+        assert abs(pc.closest_rays - cnt.closest_rays) <= max(8, cnt.closest_rays * 5e-4)
+    assert tot / npx < TOL_L2, tot / npx
+
+
+def test_large_scene_benchmark_geometry_800x600(H, gpu_ctx):
+    """BASELINE.json configs[3] geometry at its resolution (800x600) and a reduced sample count: one whole band at that spp
+    against the oracle, whole-film properties, two lanes forced vs one lane bit-identical"""
+    W, Hh, spp = 800, 600, 32
+    hb = H.scenes.build_bunny(H.scenes.HostBackend("bunny"), W, Hh)
+    sp = hb.flatten()
+    gpu_ctx.upload(sp)
+    assert gpu_ctx.build_info().traversal_mode == 3
+    film = gpu_ctx.render(H.jp.render_params(W, Hh, spp))
+    c = gpu_ctx.counters()
+    assert c.samples == W * Hh * spp and np.isfinite(film).all() and film.min() >= 0 and film.max() <= 1
+    assert 1.9 < c.closest_rays / c.samples < 2.3 and 1.2 < c.shadow_rays / c.samples < 1.5
+    b = 17
+    p = H.jp.render_params(W, Hh, spp, shard_index=b, shard_count=30)
+    ref, cnt = H.oracle_render(sp, p, len(os.sched_getaffinity(0)))
+    d = np.sqrt(((film[b * 20:b * 20 + 20] - ref[b * 20:b * 20 + 20]) ** 2).sum(-1))
+    # This band runs through the four bunnies.  The reference's box test (geometry.cc:24 `tmax <= tmin`) drops ~3e-4 of the
+    # true nearest hits on these 0.5-unit triangles, WHICH ones depending on its rand()-driven tree (tools/ref_bvh_topology.py:
+    # two reference-style trees over this scene disagree on 140-164 of 400,000 camera rays); the oracle restates that tree, the
+    # device never drops a hit.  A dropped hit changes the whole path, so such samples differ grossly; everything else is exact.
+    exact = (film[b * 20:b * 20 + 20] == ref[b * 20:b * 20 + 20]).all(-1).mean()
+    assert exact > 0.97 and d.mean() < 1e-3 and (d > 1e-3).mean() < 0.02, (exact, d.mean())
+    assert abs(c.closest_rays / c.samples - 2.06) < 0.05
+    os.environ["JETPBRT_LANES"] = "2"
+    try:
+        two = gpu_ctx.render(H.jp.render_params(W, Hh, spp))
+    finally:
+        del os.environ["JETPBRT_LANES"]
+    assert np.array_equal(two.view(np.uint32), film.view(np.uint32))
