@@ -188,7 +188,9 @@ def main():
             rows[y0:y1] = True
         d = np.sqrt(((film[rows] - ref[rows]) ** 2).sum(-1))
         parity = {"mean_per_pixel_l2": float(d.mean()), "max_per_pixel_l2": float(d.max()), "pixels": int(d.size), "spp": spp_total,
-                  "tolerance": 1e-4, "sample": "bands b %% %d == %d of %d" % (k, idx, nbands)}
+                  "tolerance": 1e-4, "sample": "bands b %% %d == %d of %d" % (k, idx, nbands),
+                  "bit_identical": bool(np.array_equal(film[rows].view(np.uint32), ref[rows].view(np.uint32))),
+                  "libm_sincosf": int(ctx.build_info().libm_sincosf)}
         # (b) CPU baseline: the whole frame at a reduced spp (throughput does not depend on spp), 20-row tasks
         cpu_spp = 64
         pc = jp.render_params(W, H, cpu_spp, 5, 1234, sampler_mode=jp.JP_SAMPLER_STOCK_MT19937)
