@@ -107,10 +107,17 @@ class RefBackend(scenes.HostBackend):
         return out
 
 
-def oracle_render(scene_ptr, params, nthreads=8):
+def oracle_render(scene_ptr, params, nthreads=8, watertight=False):
+    """watertight=True: the reference's arithmetic with a conservative box test (oracle/pt_oracle.cc box_hit), i.e. without
+    the hits the reference's own BVH drops on finely tessellated meshes"""
     film = np.zeros((params.height, params.width, 3), np.float32)
     cnt = jp.JpCounters()
-    st = oracle_lib().jp_oracle_render(scene_ptr, C.byref(params), nthreads, ptr(film), C.byref(cnt))
+    L = oracle_lib()
+    L.jp_oracle_set_watertight(1 if watertight else 0)
+    try:
+        st = L.jp_oracle_render(scene_ptr, C.byref(params), nthreads, ptr(film), C.byref(cnt))
+    finally:
+        L.jp_oracle_set_watertight(0)
     assert st == 0
     return film, cnt
 

@@ -243,6 +243,25 @@ def test_benchmark_size_properties(H, gpu_ctx):
     assert film[256, 20, 0] > 2 * film[256, 20, 1] and film[256, 490, 1] > 2 * film[256, 490, 0]
 
 
+def test_bunny_small_vs_watertight_reference_arithmetic(H, gpu_ctx):
+    """the committed 4 x 768-triangle mesh scene against the oracle with and without its BVH dropping hits"""
+    W, Hh, spp = 160, 120, 32
+    hb, sp = _scene(H, "bunny_small", W, Hh)
+    gpu_ctx.upload(sp)
+    p = H.jp.render_params(W, Hh, spp, 5, 77)
+    film = gpu_ctx.render(p)
+    c = gpu_ctx.counters()
+    tight, cnt = H.oracle_render(sp, p, 8, watertight=True)
+    ref, _ = H.oracle_render(sp, p, 8)
+    assert l2(film, ref) < TOL_L2 and l2(film, tight) < TOL_L2
+    if gpu_ctx.build_info().libm_sincosf != 0:
+        # what is left on a mesh even then: hits in the ~1e-2-wide fp32 acceptance fringe outside a triangle (found or not
+        # depending on the leaves a tree visits) and equal-t ties at shared edges (decided by traversal order) -- the reference's
+        # own answer depends on its rand()-driven tree there.  About one sample in 3e5 on this small mesh.
+        assert (film == tight).all(-1).mean() > 0.9995
+        assert abs(c.closest_rays - cnt.closest_rays) <= 16 and abs(c.shadow_rays - cnt.shadow_rays) <= 16
+
+
 def test_bunny_scene_full_bvh(H, gpu_ctx):
     """configs[3] geometry (4 x 69,938-triangle meshes + 2 rectangles, all materials, env light) at reduced spp:
     hit records bit-exact vs the oracle's reference-style BVH, film within tolerance."""
@@ -548,12 +567,21 @@ def test_large_scene_benchmark_geometry_800x600(H, gpu_ctx):
     p = H.jp.render_params(W, Hh, spp, shard_index=b, shard_count=30)
     ref, cnt = H.oracle_render(sp, p, len(os.sched_getaffinity(0)))
     d = np.sqrt(((film[b * 20:b * 20 + 20] - ref[b * 20:b * 20 + 20]) ** 2).sum(-1))
-    # This band runs through the four bunnies.  The reference's box test (geometry.cc:24 `tmax <= tmin`) drops ~3e-4 of the
-    # true nearest hits on these 0.5-unit triangles, WHICH ones depending on its rand()-driven tree (tools/ref_bvh_topology.py:
-    # two reference-style trees over this scene disagree on 140-164 of 400,000 camera rays); the oracle restates that tree, the
-    # device never drops a hit.  A dropped hit changes the whole path, so such samples differ grossly; everything else is exact.
+    # This band runs through the four bunnies.  On such meshes the closest hit is not a function of the ray alone, in the
+    # reference either: at 358 units from the camera the fp32 edge functions of FTriangle::Intersect accept points up to ~0.01
+    # outside a triangle, i.e. outside its bounding box, so whether such a "slop" hit is found depends on which leaves the tree
+    # makes the ray visit (and the reference's box test additionally drops subtrees when rounding gives `tmax <= tmin`).  Two
+    # reference-style trees built with different rand() seeds disagree on 140-164 of 400,000 camera rays here
+    # (tools/ref_bvh_topology.py); the oracle restates one of them, the device walks its own tree.  A different hit changes the
+    # whole path, so those samples differ grossly; every other sample is bit-identical.
     exact = (film[b * 20:b * 20 + 20] == ref[b * 20:b * 20 + 20]).all(-1).mean()
     assert exact > 0.97 and d.mean() < 1e-3 and (d > 1e-3).mean() < 0.02, (exact, d.mean())
+    # the same with a conservative box test in the oracle (removes the dropped subtrees, not the slop hits): a little closer
+    tight, tcnt = H.oracle_render(sp, p, len(os.sched_getaffinity(0)), watertight=True)
+    dt = np.sqrt(((film[b * 20:b * 20 + 20] - tight[b * 20:b * 20 + 20]) ** 2).sum(-1))
+    exact_t = (film[b * 20:b * 20 + 20] == tight[b * 20:b * 20 + 20]).all(-1).mean()
+    print("band vs reference tree: exact px %.5f mean L2 %.2e | vs watertight tree: exact px %.5f mean L2 %.2e" % (exact, d.mean(), exact_t, dt.mean()))
+    assert exact_t > 0.97 and dt.mean() < 1e-3 and exact_t >= exact - 0.002
     assert abs(c.closest_rays / c.samples - 2.06) < 0.05
     os.environ["JETPBRT_LANES"] = "2"
     try:

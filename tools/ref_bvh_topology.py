@@ -1,8 +1,9 @@
-"""The reference's BVH (bvh.h:54-146: random split axis from libc rand(), median split, no box padding except for flat
-boxes) drops true nearest hits: FBounds3::Intersect (geometry.cc:10-30) rejects a box when `tmax <= tmin`, which rounding
-makes true for rays that graze a box edge.  On the 280k-triangle scene two reference-style trees built with different
-rand() seeds therefore return DIFFERENT closest hits for the same ray on ~3.5e-4 of the camera rays through the meshes.
-CPU only (uses the oracle's restatement of that tree, which is pinned bit-exact to the compiled reference)."""
+"""On finely tessellated meshes the reference's closest hit depends on its BVH topology (bvh.h:54-146: random split axis from
+libc rand(), median split): far from the camera the fp32 edge functions of FTriangle::Intersect accept points ~0.01 outside a
+triangle -- outside its bounding box -- so such hits are found or not depending on the leaves a ray visits, and
+FBounds3::Intersect (geometry.cc:10-30) additionally drops a subtree when rounding gives `tmax <= tmin`.  On the 280k-triangle
+scene two reference-style trees built with different rand() seeds return DIFFERENT closest hits for ~3.5e-4 of the camera rays
+through the meshes.  CPU only (uses the oracle's restatement of that tree, which is pinned bit-exact to the compiled reference)."""
 import os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
