@@ -93,6 +93,13 @@ typedef struct JpScene {
      * the device from the primitive extents (LBVH; replaces the host build of FScene::Preprocess, scene.cc:11-23). */
     int32_t n_bvh_nodes;   const float *bvh_bounds; const int32_t *bvh_left, *bvh_right;
     int32_t n_bvh_prim_indices; const int32_t *bvh_prim_index;
+    /* 0: the hierarchy is acceleration only -- the library is free to re-shape it (8-wide shadow tree, flat leaf list) and
+     *    tests boxes conservatively, so no hit is ever dropped.
+     * 1: REFERENCE SEMANTICS -- the given tree is walked node for node the way FBVH_Node::Intersect does (bvh.h:94-103: box
+     *    test of geometry.cc:10-30 with its `tmax <= tmin` rejection on the unpadded bounds, left subtree then right, leaf
+     *    objects in order).  With the reference's own tree (host: FScene::referenceTree) the hits are then the reference's hits
+     *    even where those depend on its topology (finely tessellated meshes, DESIGN.md "Numerics").  Several times slower. */
+    int32_t bvh_reference_semantics;
 } JpScene;
 
 typedef struct JpRenderParams {

@@ -41,6 +41,7 @@ class JpScene(C.Structure):
         ("world_radius", C.c_float),
         ("n_bvh_nodes", C.c_int32), ("bvh_bounds", _fp), ("bvh_left", _ip), ("bvh_right", _ip),
         ("n_bvh_prim_indices", C.c_int32), ("bvh_prim_index", _ip),
+        ("bvh_reference_semantics", C.c_int32),
     ]
 
 
@@ -102,6 +103,7 @@ def host_lib():
         L.jp_host_scene_sphere.argtypes = [C.c_void_p, _fp, C.c_float, C.c_int, _fp]
         L.jp_host_scene_preprocess.argtypes = [C.c_void_p]
         L.jp_host_scene_set_device_build.argtypes = [C.c_void_p, C.c_int]
+        L.jp_host_scene_set_reference_tree.argtypes = [C.c_void_p, C.c_int]
         L.jp_host_num_primitives.argtypes = [C.c_void_p]
         L.jp_host_num_lights.argtypes = [C.c_void_p]
         L.jp_host_flatten.restype = C.POINTER(JpScene)

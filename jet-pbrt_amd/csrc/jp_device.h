@@ -189,6 +189,54 @@ __device__ __forceinline__ int traverse(NodePtr nodes, PrimPtr prims, V3 o, V3 d
 	return hit;
 }
 
+// REFERENCE SEMANTICS (JpScene.bvh_reference_semantics): the caller's tree walked node for node the way the reference does.
+// FBVH_Node::Intersect bvh.h:94-103: box test on the node's own unpadded bounds, then the left subtree, then the right one,
+// no ordering by distance; FBVH_NodeLeaf::Intersect bvh.h:132-142: every object of the leaf in order; every accepted hit
+// shrinks ray.max_t, which later box tests see.  FBounds3::Intersect geometry.cc:10-30 verbatim: per axis two IEEE divisions,
+// std::min / std::max argument order, `tmax <= tmin` rejects.  With the reference's own tree this returns the reference's hit
+// even where that depends on the topology (hits in the fp32 acceptance fringe outside a triangle's box, subtrees dropped by
+// the strict box test).  nodes: 2 x float4 per node, (min xyz, left bits) (max xyz, right bits); left < 0: leaf with device
+// primitives [-(left) - 1, + right).
+template <bool kAnyHit>
+__device__ __forceinline__ int traverse_ref(const float4* __restrict__ nodes, const float4* __restrict__ prims, V3 o, V3 d, float tmin, float& tmax, int* stack)
+{
+	int hit = -1, sp = 0, cur = 0;
+	for (;;)
+	{
+		const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+		float bt0 = tmin, bt1 = tmax;
+		bool ok;
+		{
+			const float lo = (n0.x - o.x) / d.x, hi = (n1.x - o.x) / d.x;
+			bt0 = smax(smin(lo, hi), bt0); bt1 = smin(smax(lo, hi), bt1);
+			ok = !(bt1 <= bt0);
+		}
+		if (ok)
+		{
+			const float lo = (n0.y - o.y) / d.y, hi = (n1.y - o.y) / d.y;
+			bt0 = smax(smin(lo, hi), bt0); bt1 = smin(smax(lo, hi), bt1);
+			ok = !(bt1 <= bt0);
+		}
+		if (ok)
+		{
+			const float lo = (n0.z - o.z) / d.z, hi = (n1.z - o.z) / d.z;
+			bt0 = smax(smin(lo, hi), bt0); bt1 = smin(smax(lo, hi), bt1);
+			ok = !(bt1 <= bt0);
+		}
+		const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+		if (ok && left >= 0) { stack[sp * JP_BLOCK] = right; sp++; cur = left; continue; }
+		if (ok)
+		{
+			const int first = -left - 1;
+			for (int k = 0; k < right; k++)
+				if (prim_hit<4>(prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) return hit; }
+		}
+		if (sp == 0) break;
+		sp--; cur = stack[sp * JP_BLOCK];
+	}
+	return hit;
+}
+
 // Tiny scenes (<= 32 BVH leaves, e.g. the 32-triangle Cornell box): the tree is collapsed into ONE wide node whose
 // children are the leaves.  Phase 1 tests every leaf box with wave-UNIFORM control flow and uniform (scalar /
 // broadcast) operands -- no stack, no pointer chasing, all 64 lanes busy -- and records the boxes the ray enters

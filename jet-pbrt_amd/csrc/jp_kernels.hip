@@ -166,6 +166,7 @@ extern __shared__ float4 s_dyn[];      // 16-byte aligned base
 // kMode 1: BVH + primitives staged into LDS next to the stack
 // kMode 2: tiny scene: flat leaf list (uniform loads from global), primitives in LDS, no stack
 // kMode 3: large scene: 8-wide quantised BVH in global memory, (group, hits) stack pairs in LDS
+// kMode 5: reference semantics: the caller's tree node for node, unordered, the reference's box test (traverse_ref)
 template <int kMode>
 struct SceneAccess;
 template <> struct SceneAccess<0>
@@ -211,6 +212,14 @@ template <> struct SceneAccess<3>
 	__device__ __forceinline__ SceneAccess(const SceneView& sc, int) : prims(sc.prims), stack((unsigned int*)s_dyn + threadIdx.x) {}
 	template <bool kAnyHit> __device__ __forceinline__ int trace(const SceneView& sc, V3 o, V3 d, float tmin, float& tmax) const
 	{ return traverse_wide<kAnyHit>(sc.wide, prims, o, d, tmin, tmax, stack); }
+};
+
+template <> struct SceneAccess<5>
+{
+	const float4 *nodes, *prims; int* stack;
+	__device__ __forceinline__ SceneAccess(const SceneView& sc, int) : nodes(sc.nodes), prims(sc.prims), stack((int*)s_dyn + threadIdx.x) {}
+	template <bool kAnyHit> __device__ __forceinline__ int trace(const SceneView&, V3 o, V3 d, float tmin, float& tmax) const
+	{ return traverse_ref<kAnyHit>(nodes, prims, o, d, tmin, tmax, stack); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -736,6 +745,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	if (s->n_triangles < 0 || s->n_rectangles < 0 || s->n_spheres < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_bvh_nodes < 0 || s->n_bvh_prim_indices < 0)
 		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: negative count");
 	const bool device_build = s->n_bvh_nodes == 0;              // no hierarchy handed over: build it on the device (jp_lbvh.h)
+	const bool ref_sem = !device_build && s->bvh_reference_semantics == 1;   // walk the caller's tree with the reference's semantics (traverse_ref)
 	if (!s->prim_shape_type || !s->prim_shape_index || !s->prim_material || !s->prim_light || (!device_build && (!s->bvh_bounds || !s->bvh_left || !s->bvh_right || !s->bvh_prim_index)))
 		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: null array");
 	if ((s->n_triangles && (!s->tri_p0 || !s->tri_p1 || !s->tri_p2 || !s->tri_n)) || (s->n_rectangles && (!s->rect_p0 || !s->rect_p1 || !s->rect_p2 || !s->rect_p3 || !s->rect_n))
@@ -823,8 +833,8 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	// ---- large scenes: collapse the binary tree into 8-wide nodes with quantised child boxes (traverse_wide) ----
 	int nleaves_total = 0; for (int n = 0; n < s->n_bvh_nodes; n++) if (seen[n] && s->bvh_left[n] < 0) nleaves_total++;
 	std::vector<uint32_t> wide; int wide_height = 0;
-	bool use_wide = !device_build && nleaves_total > 32 && s->bvh_left[0] >= 0;
-	if (!device_build)
+	bool use_wide = !device_build && !ref_sem && nleaves_total > 32 && s->bvh_left[0] >= 0;
+	if (!device_build && !ref_sem)
 	{
 		size_t est = ((size_t)s->n_bvh_nodes + (size_t)s->n_primitives) * 80;                            // LDS-resident scenes keep the binary tree
 		if (est + (size_t)(height + 2) * JP_BLOCK * sizeof(int) <= 40 * 1024) use_wide = false;
@@ -944,9 +954,30 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 
 	// binary device tree (small and medium scenes): interior nodes get device indices in DFS order
 	std::vector<int> order;
-	if (!device_build) { std::vector<int> st; st.push_back(0); while (!st.empty()) { int n = st.back(); st.pop_back(); if (s->bvh_left[n] < 0) continue; hostToDevNode[n] = (int)order.size(); order.push_back(n); st.push_back(s->bvh_right[n]); st.push_back(s->bvh_left[n]); } }
+	if (!device_build && !ref_sem) { std::vector<int> st; st.push_back(0); while (!st.empty()) { int n = st.back(); st.pop_back(); if (s->bvh_left[n] < 0) continue; hostToDevNode[n] = (int)order.size(); order.push_back(n); st.push_back(s->bvh_right[n]); st.push_back(s->bvh_left[n]); } }
 	const float kEmpty[6] = { 1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f };
 	if (device_build) {}
+	else if (ref_sem)
+	{   // the caller's nodes under their own indices, unpadded boxes; primitives in the leaves' visiting order (left before right)
+		nodes.assign((size_t)2 * s->n_bvh_nodes, make_float4(0, 0, 0, 0));
+		std::vector<int> st; st.push_back(0);
+		while (!st.empty())
+		{
+			const int n = st.back(); st.pop_back();
+			const float* b = s->bvh_bounds + 6 * (size_t)n;
+			int l = s->bvh_left[n], r = s->bvh_right[n];
+			if (l < 0)
+			{
+				const int first = -l - 1, cnt = r;
+				const int dfirst = (int)meta.size();
+				for (int k = 0; k < cnt; k++) emit_prim(s->bvh_prim_index[first + k]);
+				l = -dfirst - 1;
+			}
+			else { st.push_back(r); st.push_back(l); }
+			float fl, fr; std::memcpy(&fl, &l, 4); std::memcpy(&fr, &r, 4);
+			nodes[2 * (size_t)n] = make_float4(b[0], b[1], b[2], fl); nodes[2 * (size_t)n + 1] = make_float4(b[3], b[4], b[5], fr);
+		}
+	}
 	else if (order.empty())
 	{   // the root itself is a leaf: a synthetic interior root whose right child can never be hit
 		float lb[6]; pad_box(0, lb);
@@ -995,11 +1026,11 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		height = lr.height; c->build_ms = lr.build_ms;
 		n4nodes = (size_t)4 * lr.n_nodes; n4prims = (size_t)4 * s->n_primitives; nmeta = (size_t)s->n_primitives;
 	}
-	c->bvh_height = height; c->bvh_nodes = (int)(n4nodes / 4);
+	c->bvh_height = height; c->bvh_nodes = ref_sem ? s->n_bvh_nodes : (int)(n4nodes / 4);
 
 	// tiny scenes: the flat leaf list of traverse_flat (leaf boxes padded like the node boxes, list padded to x4)
 	std::vector<float4> flat; std::vector<int> flat_leaf;
-	if (!device_build)
+	if (!device_build && !ref_sem)
 	{
 		int nleaves = 0; for (int n = 0; n < s->n_bvh_nodes; n++) if (seen[n] && s->bvh_left[n] < 0) nleaves++;
 		if (nleaves <= 32)
@@ -1079,6 +1110,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	c->trav_mode = use_wide ? 3 : ((!flat.empty() && prim_bytes <= 40 * 1024) ? 2 : (c->scene_in_lds ? 1 : 0));
 	if (!use_wide) if (const char* e = getenv("JETPBRT_TRAVERSAL")) { int m = atoi(e); if (m == 0 || (m == 1 && c->scene_in_lds)) c->trav_mode = m; }   // experiments: force a lower mode
 	if (use_wide) c->scene_in_lds = false;
+	if (ref_sem) c->trav_mode = 5;
 	// large scenes: closest-hit rays walk the binary tree (exact near-to-far order, early out), any-hit shadow rays the
 	// 8-wide quantised tree (fewest node fetches; order irrelevant).  Measured on the 280k-triangle scene:
 	// k_extend 10.3 ms binary vs 13.8 ms wide, k_shadow 10.6 ms binary vs 8.6 ms wide.
@@ -1199,7 +1231,8 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 				}
 				{
 					Stamper t(c, CLS_EXTEND);
-					if (c->trav_mode == 2) hipLaunchKernelGGL(k_extend<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
+					if (c->trav_mode == 5) hipLaunchKernelGGL(k_extend<5>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
+					else if (c->trav_mode == 2) hipLaunchKernelGGL(k_extend<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
 					else if (c->trav_mode == 1) hipLaunchKernelGGL(k_extend<1>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
 					else hipLaunchKernelGGL(k_extend<0>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
 				}
@@ -1216,6 +1249,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 				{
 					Stamper t(c, CLS_SHADOW);
 					if (c->trav_mode == 3) hipLaunchKernelGGL(k_shadow<3>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes_shadow, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
+					else if (c->trav_mode == 5) hipLaunchKernelGGL(k_shadow<5>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 					else if (c->trav_mode == 2) hipLaunchKernelGGL(k_shadow<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 					else if (c->trav_mode == 1) hipLaunchKernelGGL(k_shadow<1>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 					else hipLaunchKernelGGL(k_shadow<0>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
@@ -1413,6 +1447,7 @@ int jp_trace(JpContext* c, int32_t n, const float* origin, const float* dir, con
 		hipMemcpyAsync(d_t0, tmin, (size_t)n * 4, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(d_t1, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
 		int grid = std::min(c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK);
 		if (c->trav_mode == 3 && getenv("JETPBRT_TRACE_WIDE")) hipLaunchKernelGGL(k_trace<3>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes_shadow, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
+		else if (c->trav_mode == 5) hipLaunchKernelGGL(k_trace<5>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		else if (c->trav_mode == 2) hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		else if (c->trav_mode == 1) hipLaunchKernelGGL(k_trace<1>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		else hipLaunchKernelGGL(k_trace<0>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);

@@ -121,4 +121,106 @@ void BuildBVH(const std::vector<FBounds3>& primBounds, FlatBVH& out, int maxLeaf
 	b.build(0, (int)pb.size());
 }
 
+// ---- the reference's own tree, node for node -------------------------------------------------------------------------
+// On finely tessellated meshes the reference's closest hit depends on its tree (DESIGN.md "Numerics": fp32 acceptance
+// fringe outside triangle boxes, dropped subtrees), so reproducing its film bit for bit there takes ITS tree: FBVH_Node
+// (bvh.h:54-91) draws the split axis with random_int(0, 2) = (int)(0 + 3 * (rand() * (1.0f / (RAND_MAX + 1.0f))))
+// (pbrt.h:106-120), std::sorts the range by bounds.min[axis], splits at the median and stops at <= 5 objects; a
+// reference process never calls srand, so the sequence is glibc's rand() from its default seed 1 -- restated here
+// (TYPE_3 additive feedback generator, r[i] = r[i-3] + r[i-31], 310 outputs discarded) so that the build neither depends on
+// nor disturbs the process-wide rand() state.  std::sort is the same libstdc++ introsort the reference build uses, and it
+// is applied to the same sequence of (sub)ranges, so equal keys land where they land in the reference.
+// An interior node whose only child is a leaf (span <= 5) is emitted as that leaf: its box is the leaf's box.
+namespace
+{
+struct GlibcRand
+{
+	int32_t r[34]; int f, b;                                                  // f = front, b = rear of the 31-word state
+	explicit GlibcRand(uint32_t seed)
+	{
+		int32_t st[31];
+		st[0] = (int32_t)(seed ? seed : 1u);
+		for (int i = 1; i < 31; i++)
+		{
+			long hi = st[i - 1] / 127773, lo = st[i - 1] % 127773;              // 16807 * x mod (2^31 - 1) without overflow
+			long w = 16807 * lo - 2836 * hi;
+			if (w < 0) w += 2147483647;
+			st[i] = (int32_t)w;
+		}
+		for (int i = 0; i < 31; i++) r[i] = st[i];
+		f = 3; b = 0;
+		for (int i = 0; i < 310; i++) next();
+	}
+	int next()
+	{
+		uint32_t v = (uint32_t)r[f] + (uint32_t)r[b];
+		r[f] = (int32_t)v;
+		const int result = (int)(v >> 1);
+		if (++f >= 31) f = 0;
+		if (++b >= 31) b = 0;
+		return result;
+	}
+};
+
+struct RefBuilder
+{
+	const std::vector<B>& pb; std::vector<int32_t> order; FlatBVH& out; GlibcRand rng;
+	RefBuilder(const std::vector<B>& pb, FlatBVH& out) : pb(pb), out(out), rng(1) { order.resize(pb.size()); for (size_t i = 0; i < pb.size(); i++) order[i] = (int32_t)i; }
+	int random_axis()
+	{
+		const float r = (float)rng.next() * (1.0f / (2147483647 + 1.0f));    // pbrt.h:106-108, RAND_MAX = 2147483647
+		const float v = 0.0f + (3.0f - 0.0f) * r;                                // pbrt.h:110-114
+		return (int)v;                                                           // pbrt.h:116-120
+	}
+	int emit(const B& b)
+	{
+		int n = (int)out.left.size();
+		out.left.push_back(0); out.right.push_back(0);
+		for (int a = 0; a < 3; a++) out.bounds.push_back(b.mn[a]);
+		for (int a = 0; a < 3; a++) out.bounds.push_back(b.mx[a]);
+		return n;
+	}
+	void setBox(int n, const B& b) { for (int a = 0; a < 3; a++) { out.bounds[6 * n + a] = b.mn[a]; out.bounds[6 * n + 3 + a] = b.mx[a]; } }
+	int build(size_t start, size_t end, B& boxOut)
+	{
+		const int axis = random_axis();                                          // drawn for every node, leaves included (bvh.h:61)
+		const size_t span = end - start;
+		const int me = emit(emptyB());
+		if (span <= 5)                                                           // MAX_HITTABLES_IN_LEAF
+		{
+			B bb = emptyB();
+			for (size_t i = start; i < end; i++) grow(bb, pb[order[i]]);
+			out.left[me] = -((int32_t)out.prim_index.size()) - 1; out.right[me] = (int32_t)span;
+			for (size_t i = start; i < end; i++) out.prim_index.push_back(order[i]);
+			setBox(me, bb); boxOut = bb;
+			return me;
+		}
+		const std::vector<B>& boxes = pb;
+		std::sort(order.begin() + start, order.begin() + end, [&boxes, axis](int32_t x, int32_t y) { return boxes[x].mn[axis] < boxes[y].mn[axis]; });
+		const size_t mid = start + span / 2;
+		B bl, br;
+		const int l = build(start, mid, bl);
+		const int r = build(mid, end, br);
+		out.left[me] = l; out.right[me] = r;
+		B bb = bl; grow(bb, br);
+		setBox(me, bb); boxOut = bb;
+		return me;
+	}
+};
+}
+
+void BuildReferenceBVH(const std::vector<FBounds3>& primWorldBounds, FlatBVH& out)
+{
+	out = FlatBVH();
+	if (primWorldBounds.empty()) return;
+	std::vector<B> pb(primWorldBounds.size());
+	for (size_t i = 0; i < pb.size(); i++)
+	{
+		pb[i].mn[0] = primWorldBounds[i]._min.x; pb[i].mn[1] = primWorldBounds[i]._min.y; pb[i].mn[2] = primWorldBounds[i]._min.z;
+		pb[i].mx[0] = primWorldBounds[i]._max.x; pb[i].mx[1] = primWorldBounds[i]._max.y; pb[i].mx[2] = primWorldBounds[i]._max.z;
+	}
+	RefBuilder b(pb, out);
+	B root; b.build(0, pb.size(), root);
+}
+
 } // namespace jetpbrt

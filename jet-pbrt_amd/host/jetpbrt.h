@@ -259,10 +259,17 @@ public:
 	// jp_upload_scene builds an LBVH on the device.  Setup drops from ~0.3 s to a few ms on the 280k-triangle scene at
 	// the price of a lower-quality tree: meant for previews / low spp.  Default from env JETPBRT_DEVICE_BVH=1.
 	bool deviceBuild = false;
+	// true: Preprocess() builds the reference's own tree (BuildReferenceBVH: its rand() sequence from the default seed, its
+	// std::sort, median split, leaves <= 5, over the reference's WorldBounds) and the flattened scene asks the device to walk
+	// it with the reference's semantics (JpScene.bvh_reference_semantics): the film then equals the reference's bit for bit on
+	// tessellated meshes too, at several times the traversal cost.  Default from env JETPBRT_REFERENCE_TREE=1.
+	bool referenceTree = false;
 };
 
 // binned-SAH BVH over primitive bounds -> the flat node arrays of JpScene (own topology)
 void BuildBVH(const std::vector<FBounds3>& primBounds, FlatBVH& out, int maxLeaf = 4);
+// the reference's tree node for node (bvh.h:54-146 with glibc's rand() from seed 1), over the reference's WorldBounds
+void BuildReferenceBVH(const std::vector<FBounds3>& primWorldBounds, FlatBVH& out);
 
 // the flattener: owns the SoA storage a JpScene view points into
 struct FlatScene

@@ -226,6 +226,11 @@ class HostBackend:
     def preprocess(self):
         self._f("scene_preprocess")(self.h)
 
+    def set_reference_tree(self, on=True):
+        """FScene::referenceTree: build the reference's own tree (its rand() sequence, its std::sort) and have the device
+        walk it with the reference's semantics -- bit-identical hits on meshes, several times slower (host backend only)."""
+        self._f("scene_set_reference_tree")(self.h, 1 if on else 0)
+
     def set_device_build(self, on=True):
         """FScene::deviceBuild: leave the hierarchy to jp_upload_scene's device LBVH pass (host backend only)."""
         self._f("scene_set_device_build")(self.h, 1 if on else 0)

@@ -961,6 +961,29 @@ int jp_oracle_render(const JpScene* js, const JpRenderParams* rp, int nthreads, 
 void* jp_oracle_scene_new(const JpScene* js) { return new Scene(js); }
 void  jp_oracle_scene_free(void* h) { delete (Scene*)h; }
 void  jp_oracle_set_watertight(int on) { g_watertight = on != 0; }
+// debug: the tree in preorder, an interior node whose only child is a leaf reported as that leaf.  boxes: 6 floats per node,
+// kind: -1 interior, else the number of objects of the leaf; order: the objects of the leaves in visiting order.
+static void dbg_dump(const Scene& sc, int n, std::vector<float>& boxes, std::vector<int>& kind, std::vector<int>& order)
+{
+	const Node& nd = sc.nodes[n];
+	const bool single = !nd.leaf && nd.right < 0;
+	const Node& use = single ? sc.nodes[nd.left] : nd;
+	boxes.push_back(nd.box.mn.x); boxes.push_back(nd.box.mn.y); boxes.push_back(nd.box.mn.z); boxes.push_back(nd.box.mx.x); boxes.push_back(nd.box.mx.y); boxes.push_back(nd.box.mx.z);
+	if (use.leaf) { kind.push_back(use.count); for (int i = 0; i < use.count; i++) order.push_back(sc.order[use.first + i]); return; }
+	kind.push_back(-1);
+	dbg_dump(sc, nd.left, boxes, kind, order);
+	if (nd.right >= 0) dbg_dump(sc, nd.right, boxes, kind, order);
+}
+int jp_oracle_tree_dump(void* h, float* boxes, int* kind, int* order, int max_nodes)
+{
+	const Scene& sc = *(Scene*)h;
+	std::vector<float> b; std::vector<int> k, o;
+	if (sc.root >= 0) dbg_dump(sc, sc.root, b, k, o);
+	if ((int)k.size() > max_nodes) return -(int)k.size();
+	std::memcpy(boxes, b.data(), b.size() * sizeof(float)); std::memcpy(kind, k.data(), k.size() * sizeof(int)); std::memcpy(order, o.data(), o.size() * sizeof(int));
+	return (int)k.size();
+}
+
 // debug: the chain of nodes from the root to the leaf that holds `prim`; for each, its box and whether the box test lets
 // the ray in.  out: 8 floats per level (min xyz, max xyz, box test result, is leaf); returns the number of levels.
 static bool dbg_find(const Scene& sc, int n, int prim, std::vector<int>& path)

@@ -36,6 +36,8 @@ def oracle_lib():
         L.jp_oracle_scene_new.argtypes = [C.POINTER(jp.JpScene)]
         L.jp_oracle_scene_free.argtypes = [_vp]
         L.jp_oracle_trace.argtypes = [_vp, C.c_int] + [_vp] * 9
+        L.jp_oracle_tree_dump.argtypes = [_vp, _vp, _vp, _vp, C.c_int]
+        L.jp_oracle_set_watertight.argtypes = [C.c_int]
         L.jp_oracle_camera_rays.argtypes = [_vp, C.c_int, _vp, _vp, _vp]
         L.jp_oracle_bsdf.argtypes = [_vp, C.c_int, C.c_int] + [_vp] * 11
         L.jp_oracle_light_sample.argtypes = [_vp, C.c_int, C.c_int] + [_vp] * 7

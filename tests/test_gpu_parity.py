@@ -589,3 +589,66 @@ def test_large_scene_benchmark_geometry_800x600(H, gpu_ctx):
     finally:
         del os.environ["JETPBRT_LANES"]
     assert np.array_equal(two.view(np.uint32), film.view(np.uint32))
+
+
+# ---- reference semantics: the reference's own tree, walked the reference's way -> its hits, bit for bit, on meshes too --------
+def _reference_tree_scene(H, name, W, Hh, builder=None):
+    hb = H.scenes.HostBackend(name)
+    hb.set_reference_tree(True)                                  # FScene::referenceTree
+    (builder or H.SCENES[name])(hb, W, Hh)
+    sp = hb.flatten()
+    assert sp.contents.bvh_reference_semantics == 1
+    return hb, sp
+
+
+@pytest.mark.parametrize("name", ["bunny_small", "misc", "cornell"])
+def test_reference_tree_films_are_bit_identical(H, gpu_ctx, name):
+    """with FScene::referenceTree the device walks the reference's tree with the reference's box test and order: hit records,
+    films and ray counts equal the oracle's (the compiled reference's) exactly -- also on the mesh scene"""
+    W, Hh, spp = 120, 90, 16
+    hb, sp = _reference_tree_scene(H, name, W, Hh)
+    gpu_ctx.upload(sp)
+    assert gpu_ctx.build_info().traversal_mode == 5
+    rng = np.random.default_rng(9)
+    m = 100000
+    o = (rng.random((m, 3)) * [500, 300, 500] - [250, -10, 250]).astype(np.float32) if name == "bunny_small" else (rng.random((m, 3)) * [500, 500, 500] + [25, 25, -530]).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:2000, 1] = 0.0
+    tmin = np.full(m, 0.001, np.float32); tmax = np.where(rng.random(m) < 0.5, np.inf, rng.random(m) * 400).astype(np.float32)
+    hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
+    H.libc_srand(1)                                              # the reference process' rand() state when it builds its tree
+    ohit, ot, oprim, onrm = _oracle_trace(H, sp, o, d, tmin, tmax)
+    assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)) and np.array_equal(prim, oprim)
+    assert np.array_equal(nrm.view(np.uint32), onrm.view(np.uint32))
+    p = H.jp.render_params(W, Hh, spp, 5, 4321)
+    film = gpu_ctx.render(p)
+    c = gpu_ctx.counters()
+    H.libc_srand(1)
+    ref, cnt = H.oracle_render(sp, p, 8)
+    if gpu_ctx.build_info().libm_sincosf != 0:
+        assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)), (l2(film, ref), (film == ref).all(-1).mean())
+        assert (c.closest_rays, c.closest_hits, c.shadow_rays, c.shadow_occluded) == (cnt.closest_rays, cnt.closest_hits, cnt.shadow_rays, cnt.shadow_occluded)
+    else:
+        assert l2(film, ref) < TOL_L2
+
+
+def test_reference_tree_large_scene_band_bit_identical(H, gpu_ctx):
+    """the 280k-triangle scene at 800x600: the band through the four bunnies, where the device's own tree and the reference's
+    give ~3e-4 of the samples different first hits, is bit-identical once the device walks the reference's tree"""
+    W, Hh, spp = 800, 600, 8
+    hb, sp = _reference_tree_scene(H, "bunny", W, Hh, builder=lambda be, w, h: H.scenes.build_bunny(be, w, h))
+    gpu_ctx.upload(sp)
+    assert gpu_ctx.build_info().traversal_mode == 5
+    b = 17
+    p = H.jp.render_params(W, Hh, spp, shard_index=b, shard_count=30)
+    film = gpu_ctx.render(p)
+    c = gpu_ctx.counters()
+    H.libc_srand(1)
+    ref, cnt = H.oracle_render(sp, p, len(os.sched_getaffinity(0)))
+    exact = (film[b * 20:b * 20 + 20] == ref[b * 20:b * 20 + 20]).all(-1).mean()
+    print("reference tree, band %d: exact px %.5f, rays gpu %d oracle %d" % (b, exact, c.closest_rays, cnt.closest_rays))
+    if gpu_ctx.build_info().libm_sincosf != 0:
+        assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+        assert (c.closest_rays, c.shadow_rays) == (cnt.closest_rays, cnt.shadow_rays)
+    else:
+        assert l2(film, ref) < 1e-3

@@ -196,3 +196,34 @@ def test_cli_usage_and_no_gpu_behaviour(H, tmp_path):
     r = subprocess.run([H.jp.CLI_PATH, "0", "1", "16", "16", "--assets", root, "--out", str(tmp_path / "o")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 3 and not (tmp_path / "o.bmp").exists()
     assert "no HIP device" in r.stderr or "not available" in r.stderr
+
+
+def test_reference_tree_builder_reproduces_the_reference_topology(H):
+    """FScene::referenceTree: the host rebuilds the reference's own BVH (glibc rand() sequence from seed 1 restated, same
+    std::sort over the same ranges).  Node for node equal to the oracle's tree, which is pinned to the compiled reference."""
+    for name, extra in (("bunny_small", None), ("misc", None)):
+        hb = H.scenes.HostBackend(name); hb.set_reference_tree(True)
+        H.SCENES[name](hb, 32, 24)
+        s = hb.flatten().contents
+        assert s.bvh_reference_semantics == 1 and s.n_bvh_nodes > 0
+        nn = s.n_bvh_nodes
+        B = np.ctypeslib.as_array(s.bvh_bounds, (nn * 6,)).reshape(nn, 6); L = np.ctypeslib.as_array(s.bvh_left, (nn,)); R = np.ctypeslib.as_array(s.bvh_right, (nn,))
+        P = np.ctypeslib.as_array(s.bvh_prim_index, (s.n_bvh_prim_indices,))
+        boxes, kind, order = [], [], []
+
+        def walk(n):
+            boxes.append(B[n]);
+            if L[n] < 0:
+                first = -L[n] - 1; kind.append(int(R[n])); order.extend(int(v) for v in P[first:first + R[n]]); return
+            kind.append(-1); walk(L[n]); walk(R[n])
+        import sys
+        sys.setrecursionlimit(10000)
+        walk(0)
+        H.libc_srand(1)                                           # the reference process' default rand() state
+        Lo = H.oracle_lib(); oh = Lo.jp_oracle_scene_new(hb.flatten())
+        ob = np.zeros((4 * s.n_primitives + 8, 6), np.float32); ok = np.zeros(4 * s.n_primitives + 8, np.int32); oo = np.zeros(s.n_primitives, np.int32)
+        n = Lo.jp_oracle_tree_dump(oh, H.ptr(ob), H.ptr(ok), H.ptr(oo), len(ok))
+        Lo.jp_oracle_scene_free(oh)
+        assert n == len(kind), (n, len(kind))
+        assert np.array_equal(ok[:n], np.array(kind, np.int32)) and np.array_equal(oo, np.array(order, np.int32))
+        assert np.array_equal(ob[:n].view(np.uint32), np.array(boxes, np.float32).view(np.uint32))
