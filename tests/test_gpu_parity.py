@@ -95,6 +95,8 @@ def test_film_vs_golden_reference_and_oracle(H, gpu_ctx, name):
     assert np.isfinite(film).all()
     assert l2(film, gold) < TOL_L2, l2(film, gold)
     assert (film == gold).all(-1).mean() > 0.8                  # most pixels are bit-identical (all of them on the host the goldens were made on)
+    if gpu_ctx.build_info().libm_sincosf != 0 and name in EXACT_SCENES:
+        assert np.array_equal(film.view(np.uint32), gold.view(np.uint32))   # the UNMODIFIED reference's film, bit for bit
     ref, ocnt = H.oracle_render(sp, p, 4)
     assert_film(gpu_ctx, film, ref, name)
     c = gpu_ctx.counters()
@@ -652,3 +654,18 @@ def test_reference_tree_large_scene_band_bit_identical(H, gpu_ctx):
         assert (c.closest_rays, c.shadow_rays) == (cnt.closest_rays, cnt.shadow_rays)
     else:
         assert l2(film, ref) < 1e-3
+
+
+@pytest.mark.parametrize("name", SCENE_NAMES)
+def test_reference_tree_reproduces_the_committed_reference_films(H, gpu_ctx, name):
+    """the golden films were written by the unmodified reference (counter sampler plugged in through FSampler); with the
+    reference's tree and semantics the device reproduces every one of them bit for bit, the mesh scene included"""
+    W = Hh = 48
+    hb, sp = _reference_tree_scene(H, name, W, Hh)
+    gpu_ctx.upload(sp)
+    film = gpu_ctx.render(H.jp.render_params(W, Hh, 8, 5, 1234))
+    gold = np.load(os.path.join(H.GOLDEN, "film_%s_counter.npy" % name))
+    if gpu_ctx.build_info().libm_sincosf != 0:
+        assert np.array_equal(film.view(np.uint32), gold.view(np.uint32)), (l2(film, gold), (film == gold).all(-1).mean())
+    else:
+        assert l2(film, gold) < TOL_L2
