@@ -96,6 +96,13 @@ public:
 	FColor LiPublic(const FRay& r, const FScene* s, FSampler* smp) const { return Li(r, s, smp); }
 };
 
+class FExposedRecursiveIntegrator : public FPathIntegratorRecursive        // integrator.h:88-106
+{
+public:
+	using FPathIntegratorRecursive::FPathIntegratorRecursive;
+	void Band(const FScene* s, FSampler* smp, FFilmView* v) const { DoRender(s, smp, v); }
+};
+
 class FBandTask : public FTask
 {
 public:
@@ -238,6 +245,25 @@ int ref_render(void* h, int W, int H, int spp, int maxdepth, int sampler_mode, u
 	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++)
 	{
 		const FColor& c = film(x, y);                                                // film.h:51
+		float* o = film_out + 3 * ((size_t)y * W + x);
+		o[0] = c.r; o[1] = c.g; o[2] = c.b;
+	}
+	return 0;
+}
+
+// FPathIntegratorRecursive over the whole frame, serial, counter sampler (for the "same estimator" check of the host alias)
+int ref_render_recursive(void* h, int W, int H, int spp, int maxdepth, unsigned seed, float* film_out)
+{
+	RefScene* rs = (RefScene*)h;
+	if (!rs->preprocessed) return -1;
+	FFilm film(W, H);
+	FExposedRecursiveIntegrator integ(maxdepth);
+	FCounterSampler sampler(spp, seed);
+	FFilmView view(&film, 0, 0, W, H);
+	integ.Band(rs->scene.get(), &sampler, &view);
+	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++)
+	{
+		const FColor& c = film(x, y);
 		float* o = film_out + 3 * ((size_t)y * W + x);
 		o[0] = c.r; o[1] = c.g; o[2] = c.b;
 	}

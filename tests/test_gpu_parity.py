@@ -669,3 +669,15 @@ def test_reference_tree_reproduces_the_committed_reference_films(H, gpu_ctx, nam
         assert np.array_equal(film.view(np.uint32), gold.view(np.uint32)), (l2(film, gold), (film == gold).all(-1).mean())
     else:
         assert l2(film, gold) < TOL_L2
+
+
+@pytest.mark.parametrize("name", ["cornell", "misc", "lights"])
+def test_recursive_integrator_alias_vs_the_reference_recursive_film(H, gpu_ctx, name):
+    """host FPathIntegratorRecursive = the same kernels; against the film of the reference's own recursive integrator the
+    difference is the rounding of the nested throughput products (~1e-8), nothing else"""
+    hb, sp = _scene(H, name, 48, 48)
+    gpu_ctx.upload(sp)
+    film = gpu_ctx.render(H.jp.render_params(48, 48, 8, 5, 1234))
+    rec = np.load(os.path.join(H.GOLDEN, "film_%s_counter_recursive.npy" % name))
+    d = np.sqrt(((film - rec) ** 2).sum(-1))
+    assert d.mean() < 1e-6 and d.max() < 1e-5, (d.mean(), d.max())

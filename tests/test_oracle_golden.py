@@ -117,3 +117,17 @@ def test_bsdf_kats(H, kat):
         assert {9, 17, 5, 6}.issubset(kinds)     # diffuse-reflection, glossy-reflection, specular reflection / transmission
     finally:
         L.jp_oracle_scene_free(oh)
+
+
+@pytest.mark.parametrize("name", ["cornell", "misc", "lights"])
+def test_recursive_integrator_is_the_same_estimator(H, name):
+    """FPathIntegratorRecursive (integrator.cc:233-307) vs FPathIntegratorIteration, both run by the UNMODIFIED reference on
+    the same counter stream (committed goldens): same draws, same decisions -- the films differ in the rounding of the
+    throughput products only.  The host layer therefore serves FPathIntegratorRecursive with the iterative kernels."""
+    it = np.load(os.path.join(H.GOLDEN, "film_%s_counter.npy" % name))
+    rec = np.load(os.path.join(H.GOLDEN, "film_%s_counter_recursive.npy" % name))
+    d = np.sqrt(((it - rec) ** 2).sum(-1))
+    assert d.mean() < 1e-7 and d.max() < 1e-6 and not np.array_equal(it, rec)
+    hb = H.SCENES[name](H.scenes.HostBackend(name), 48, 48)
+    ref, _ = H.oracle_render(hb.flatten(), H.jp.render_params(48, 48, 8, 5, 1234), 4)
+    assert np.sqrt(((ref - rec) ** 2).sum(-1)).mean() < 1e-6
