@@ -31,8 +31,8 @@ typedef enum JpStatus {
     JP_ERR_UNSUPPORTED = -5         /* e.g. sampler mode the device path cannot reproduce             */
 } JpStatus;
 
-/* shape kinds: FTriangle shape.h:277-369, FRectangle shape.h:380-472, FSphere shape.h:476-662 */
-enum { JP_SHAPE_TRIANGLE = 0, JP_SHAPE_RECTANGLE = 1, JP_SHAPE_SPHERE = 2 };
+/* shape kinds: FTriangle shape.h:277-369, FRectangle shape.h:380-472, FSphere shape.h:476-662, FDisk shape.h:189-275 */
+enum { JP_SHAPE_TRIANGLE = 0, JP_SHAPE_RECTANGLE = 1, JP_SHAPE_SPHERE = 2, JP_SHAPE_DISK = 3 };
 /* material kinds: material.h:27-41 (matte), :45-59 (mirror), :63-81 (glass), :85-110 + material.cc:12-29
  * (plastic), material.h:113-137 + material.cc:31-43 (metal) */
 enum { JP_MAT_MATTE = 0, JP_MAT_MIRROR = 1, JP_MAT_GLASS = 2, JP_MAT_PLASTIC = 3, JP_MAT_METAL = 4 };
@@ -100,6 +100,9 @@ typedef struct JpScene {
      *    objects in order).  With the reference's own tree (host: FScene::referenceTree) the hits are then the reference's hits
      *    even where those depend on its topology (finely tessellated meshes, DESIGN.md "Numerics").  Several times slower. */
     int32_t bvh_reference_semantics;
+
+    /* FDisk (shape.h:189-275): position, normal (already normalised by the constructor, shape.h:194), radius */
+    int32_t n_disks;       const float *disk_center, *disk_normal; const float *disk_radius;
 } JpScene;
 
 typedef struct JpRenderParams {

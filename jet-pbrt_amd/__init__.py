@@ -42,6 +42,7 @@ class JpScene(C.Structure):
         ("n_bvh_nodes", C.c_int32), ("bvh_bounds", _fp), ("bvh_left", _ip), ("bvh_right", _ip),
         ("n_bvh_prim_indices", C.c_int32), ("bvh_prim_index", _ip),
         ("bvh_reference_semantics", C.c_int32),
+        ("n_disks", C.c_int32), ("disk_center", _fp), ("disk_normal", _fp), ("disk_radius", _fp),
     ]
 
 
@@ -101,6 +102,7 @@ def host_lib():
         L.jp_host_scene_mesh.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, _fp, C.c_float, C.c_int, _fp]
         L.jp_host_scene_rect.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _fp]
         L.jp_host_scene_sphere.argtypes = [C.c_void_p, _fp, C.c_float, C.c_int, _fp]
+        L.jp_host_scene_disk.argtypes = [C.c_void_p, _fp, _fp, C.c_float, C.c_int, _fp]
         L.jp_host_scene_preprocess.argtypes = [C.c_void_p]
         L.jp_host_scene_set_device_build.argtypes = [C.c_void_p, C.c_int]
         L.jp_host_scene_set_reference_tree.argtypes = [C.c_void_p, C.c_int]

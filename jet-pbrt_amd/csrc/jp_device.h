@@ -123,6 +123,21 @@ __device__ __forceinline__ bool sph_hit(V3 c, float r, V3 o, V3 d, float tmin, f
 	return false;
 }
 
+// FDisk::Intersect shape.h:200-221 (isEqual of pbrt.h:97-104 with epsilon = FLT_EPSILON, Distance = sqrt of the squared length)
+__device__ __forceinline__ bool disk_hit(V3 c, float r, V3 n, V3 o, V3 d, float tmin, float& tmax)
+{
+	const float dn = dot(d, n);
+	if (fabsf(dn - 0.f) <= 1.1920928955078125e-07f * smax(1.f, smax(fabsf(dn), fabsf(0.f)))) return false;
+	const V3 op = c - o;
+	const float distance = dot(n, op) / dot(n, d);
+	if ((distance > tmin) && (distance < tmax))
+	{
+		const V3 hp = o + distance * d;
+		if (len(c - hp) <= r) { tmax = distance; return true; }
+	}
+	return false;
+}
+
 // One primitive record against the ray; FPrimitive::Intersect primitive.h:39-48.  kS = record stride in float4
 // units: 4 in global memory, 5 in LDS (the 80-byte stride spreads randomly indexed 64-byte records over all
 // bank groups instead of four).
@@ -135,6 +150,7 @@ __device__ __forceinline__ bool prim_hit(PrimPtr prims, int pi, V3 o, V3 d, floa
 	const int type = __float_as_int(g3.w);
 	if (type == JP_SHAPE_TRIANGLE) return tri_hit(xyz(g0), xyz(g1), xyz(g2), xyz(g3), o, d, tmin, tmax);
 	if (type == JP_SHAPE_SPHERE) return sph_hit(xyz(g0), g0.w, o, d, tmin, tmax);
+	if (type == JP_SHAPE_DISK) return disk_hit(xyz(g0), g0.w, xyz(g1), o, d, tmin, tmax);
 	return rect_hit(xyz(g0), xyz(g1), xyz(g2), mk(g0.w, g1.w, g2.w), xyz(g3), o, d, tmin, tmax);
 }
 

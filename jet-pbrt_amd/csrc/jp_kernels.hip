@@ -322,6 +322,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				p = o + h.x * d;                                                      // ray(distance) geometry.h:412-416
 				if (type == JP_SHAPE_TRIANGLE) N = xyz(g3);
 				else if (type == JP_SHAPE_RECTANGLE) N = dot(xyz(g3), d) <= 0 ? xyz(g3) : -xyz(g3);   // shape.h:427
+				else if (type == JP_SHAPE_DISK) N = xyz(prims[4 * pi + 1]);                           // shape.h:214
 				else { const float4 g0 = prims[4 * pi]; N = normalize(p - xyz(g0)); }              // shape.h:521
 				mat = meta.y;
 				if (meta.z >= 0 && (bounce == 0 || spec))                             // primitive.h:60-63, light.h:234-238
@@ -571,6 +572,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_trace(SceneView sc, int depth, int
 			const V3 p = ro + tmax * rd;
 			if (type == JP_SHAPE_TRIANGLE) N = xyz(g3);
 			else if (type == JP_SHAPE_RECTANGLE) N = dot(xyz(g3), rd) <= 0 ? xyz(g3) : -xyz(g3);
+			else if (type == JP_SHAPE_DISK) N = xyz(sc.prims[4 * h + 1]);
 			else N = normalize(p - xyz(sc.prims[4 * h]));
 		}
 		nrm[3 * i] = N.x; nrm[3 * i + 1] = N.y; nrm[3 * i + 2] = N.z;
@@ -742,21 +744,21 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	if (!c || !s) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: null argument");
 	// ---- validate every index on the host: a bad index must never reach a kernel ----
 	if (s->n_primitives <= 0) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: scene has no primitives");
-	if (s->n_triangles < 0 || s->n_rectangles < 0 || s->n_spheres < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_bvh_nodes < 0 || s->n_bvh_prim_indices < 0)
+	if (s->n_triangles < 0 || s->n_rectangles < 0 || s->n_spheres < 0 || s->n_disks < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_bvh_nodes < 0 || s->n_bvh_prim_indices < 0)
 		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: negative count");
 	const bool device_build = s->n_bvh_nodes == 0;              // no hierarchy handed over: build it on the device (jp_lbvh.h)
 	const bool ref_sem = !device_build && s->bvh_reference_semantics == 1;   // walk the caller's tree with the reference's semantics (traverse_ref)
 	if (!s->prim_shape_type || !s->prim_shape_index || !s->prim_material || !s->prim_light || (!device_build && (!s->bvh_bounds || !s->bvh_left || !s->bvh_right || !s->bvh_prim_index)))
 		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: null array");
 	if ((s->n_triangles && (!s->tri_p0 || !s->tri_p1 || !s->tri_p2 || !s->tri_n)) || (s->n_rectangles && (!s->rect_p0 || !s->rect_p1 || !s->rect_p2 || !s->rect_p3 || !s->rect_n))
-	    || (s->n_spheres && (!s->sph_center || !s->sph_radius)) || (s->n_materials && (!s->mat_type || !s->mat_params)) || (s->n_lights && (!s->light_type || !s->light_radiance || !s->light_prim)))
+	    || (s->n_spheres && (!s->sph_center || !s->sph_radius)) || (s->n_disks && (!s->disk_center || !s->disk_normal || !s->disk_radius)) || (s->n_materials && (!s->mat_type || !s->mat_params)) || (s->n_lights && (!s->light_type || !s->light_radiance || !s->light_prim)))
 		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: null array for a non-zero count");
 	if (s->n_lights > 255) return fail(JP_ERR_UNSUPPORTED, "jp_upload_scene: more than 255 lights are not supported by the shadow-entry packing");
 	bool hasNull = false;
 	for (int i = 0; i < s->n_primitives; i++)
 	{
 		int t = s->prim_shape_type[i], k = s->prim_shape_index[i];
-		int lim = t == JP_SHAPE_TRIANGLE ? s->n_triangles : t == JP_SHAPE_RECTANGLE ? s->n_rectangles : t == JP_SHAPE_SPHERE ? s->n_spheres : -1;
+		int lim = t == JP_SHAPE_TRIANGLE ? s->n_triangles : t == JP_SHAPE_RECTANGLE ? s->n_rectangles : t == JP_SHAPE_SPHERE ? s->n_spheres : t == JP_SHAPE_DISK ? s->n_disks : -1;
 		if (lim < 0 || k < 0 || k >= lim) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: primitive shape reference out of range");
 		if (s->prim_material[i] < -1 || s->prim_material[i] >= s->n_materials) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: primitive material out of range");
 		if (s->prim_light[i] < -1 || s->prim_light[i] >= s->n_lights) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: primitive light out of range");
@@ -816,6 +818,11 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 			g[1] = make_float4(s->rect_p1[3 * i], s->rect_p1[3 * i + 1], s->rect_p1[3 * i + 2], s->rect_p3[3 * i + 1]);
 			g[2] = make_float4(s->rect_p2[3 * i], s->rect_p2[3 * i + 1], s->rect_p2[3 * i + 2], s->rect_p3[3 * i + 2]);
 			g[3] = make_float4(s->rect_n[3 * i], s->rect_n[3 * i + 1], s->rect_n[3 * i + 2], 0);
+		}
+		else if (t == JP_SHAPE_DISK)
+		{
+			g[0] = make_float4(s->disk_center[3 * i], s->disk_center[3 * i + 1], s->disk_center[3 * i + 2], s->disk_radius[i]);
+			g[1] = make_float4(s->disk_normal[3 * i], s->disk_normal[3 * i + 1], s->disk_normal[3 * i + 2], 0);
 		}
 		else g[0] = make_float4(s->sph_center[3 * i], s->sph_center[3 * i + 1], s->sph_center[3 * i + 2], s->sph_radius[i]);
 		int tb = t; std::memcpy(&g[3].w, &tb, 4);
@@ -1067,6 +1074,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 			int t = s->prim_shape_type[p], k = s->prim_shape_index[p]; float area;
 			if (t == JP_SHAPE_TRIANGLE) area = 0.5f * hlen(hcross(hsub(hld(s->tri_p1 + 3 * k), hld(s->tri_p0 + 3 * k)), hsub(hld(s->tri_p2 + 3 * k), hld(s->tri_p0 + 3 * k))));
 			else if (t == JP_SHAPE_RECTANGLE) area = hlen(hcross(hsub(hld(s->rect_p0 + 3 * k), hld(s->rect_p1 + 3 * k)), hsub(hld(s->rect_p2 + 3 * k), hld(s->rect_p1 + 3 * k))));
+			else if (t == JP_SHAPE_DISK) { const float kPi = (float)3.14159265358979323846; area = kPi * s->disk_radius[k] * s->disk_radius[k]; }   // shape.h:253
 			else { const float kPi = (float)3.14159265358979323846; float r2 = s->sph_radius[k] * s->sph_radius[k]; area = 4 * kPi * r2; }
 			inv_area = 1 / area;
 		}

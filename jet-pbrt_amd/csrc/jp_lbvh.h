@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) k_lbvh_bounds(const float4* __restrict__ 
 	{
 		const float4 g0 = prims0[4 * p], g1 = prims0[4 * p + 1], g2 = prims0[4 * p + 2], g3 = prims0[4 * p + 3];
 		const int type = __float_as_int(g3.w);
-		if (type == JP_SHAPE_SPHERE)
+		if (type == JP_SHAPE_SPHERE || type == JP_SHAPE_DISK)          // disk record: (position, radius): its bounding sphere's box
 		{
 			l[0] = g0.x - g0.w; l[1] = g0.y - g0.w; l[2] = g0.z - g0.w; h[0] = g0.x + g0.w; h[1] = g0.y + g0.w; h[2] = g0.z + g0.w;
 		}

@@ -142,10 +142,9 @@ __device__ __forceinline__ bool is_delta(const Closure& c) { return c.kind == CL
 struct BsdfSample { V3 f, wi; float pdf; int flags; };
 
 // ---- sampling warps (sampling.h) ---------------------------------------------------------------------------------
-__device__ __forceinline__ V3 cosine_hemisphere(float ux, float uy)                     // sampling.h:25-59
+__device__ __forceinline__ void concentric_disk(float ux, float uy, float& px, float& py)   // sampling.h:25-50
 {
 	ux = ux * 2.f - 1.f; uy = uy * 2.f - 1.f;
-	float px, py;
 	if (ux == 0 && uy == 0) { px = 0; py = 0; }
 	else
 	{
@@ -155,6 +154,10 @@ __device__ __forceinline__ V3 cosine_hemisphere(float ux, float uy)             
 		float st, ct; sincos_f(theta, &st, &ct);
 		px = ct * radius; py = st * radius;
 	}
+}
+__device__ __forceinline__ V3 cosine_hemisphere(float ux, float uy)                     // sampling.h:53-59
+{
+	float px, py; concentric_disk(ux, uy, px, py);
 	float z = sqrtf(smax(0.f, 1 - px * px - py * py));
 	return mk(px, py, z);
 }
@@ -443,8 +446,14 @@ __device__ __forceinline__ LightSample sample_li(const SceneView& sc, PrimPtr pr
 			float su0 = sqrtf(ux); float bx = 1 - su0, by = uy * su0;
 			lp = bx * xyz(g0) + by * xyz(g1) + (1 - bx - by) * xyz(g2);
 		}
+		else if (type == JP_SHAPE_DISK)                           // FDisk::SamplePosition shape.h:256-268: g0 = (position, radius), g1 = normal
+		{
+			const Frame fr = frame_from_z(xyz(g1));
+			float px, py; concentric_disk(ux, uy, px, py);
+			lp = xyz(g0) + g0.w * (fr.s * px + fr.t * py);
+		}
 		else lp = xyz(g1) + (xyz(g0) - xyz(g1)) * ux + (xyz(g2) - xyz(g1)) * uy;   // shape.h:459-467
-		ln = xyz(g3);
+		ln = type == JP_SHAPE_DISK ? xyz(g1) : xyz(g3);
 		pdf = inv_area;
 		V3 wi = lp - p;                                           // FShape::SampleDirection shape.h:124-145
 		float dist2 = len2(wi);

@@ -70,6 +70,9 @@ void jp_host_scene_rect(void* h, int axis, float a0, float a1, float b0, float b
 void jp_host_scene_sphere(void* h, const float* center, float radius, int mat, const float* radiance)
 { HostScene* hs = (HostScene*)h; attach(hs, hs->scene->CreateShape<FSphere>(V3(center), radius), mat, radiance); }
 
+void jp_host_scene_disk(void* h, const float* pos, const float* normal, float radius, int mat, const float* radiance)
+{ HostScene* hs = (HostScene*)h; attach(hs, hs->scene->CreateShape<FDisk>(V3(pos), V3(normal), radius), mat, radiance); }
+
 void jp_host_scene_set_reference_tree(void* h, int on) { ((HostScene*)h)->scene->referenceTree = on != 0; }
 void jp_host_scene_set_device_build(void* h, int on) { ((HostScene*)h)->scene->deviceBuild = on != 0; }
 void jp_host_scene_preprocess(void* h) { HostScene* hs = (HostScene*)h; hs->scene->Preprocess(); hs->flattened = false; }

@@ -109,6 +109,14 @@ public:
 	FVector3 center; Float radius;
 };
 
+class FDisk : public FShape                                      // shape.h:189-275
+{
+public:
+	FDisk(const FPoint3& pos, const FVector3& normal, Float radius);
+	int Kind() const override { return JP_SHAPE_DISK; }
+	FPoint3 position; FVector3 normal; Float radius;             // normal normalised by the constructor (shape.h:194)
+};
+
 // triangulated OBJ ingest with the reference's transform order (shape.cc:23-68): z flip, scale, offset
 bool LoadTriangleMesh(const char* filename, std::vector<std::shared_ptr<FTriangle>>& outTriangles, bool flip_normal = false,
                       bool bFlipHandedness = false, const FVector3& offset = FVector3(0, 0, 0), Float inScale = 1.f);
@@ -276,6 +284,7 @@ struct FlatScene
 {
 	JpScene view;
 	std::vector<float> tri_p0, tri_p1, tri_p2, tri_n, rect_p0, rect_p1, rect_p2, rect_p3, rect_n, sph_center, sph_radius;
+	std::vector<float> disk_center, disk_normal, disk_radius;
 	std::vector<int32_t> prim_shape_type, prim_shape_index, prim_material, prim_light, mat_type, light_type, light_prim;
 	std::vector<float> mat_params, light_radiance, light_vec;
 	FlatBVH bvh;

@@ -72,6 +72,24 @@ FSphere::FSphere(const FVector3& c, Float r) : center(c), radius(r)
 	tightBox = worldBox;
 }
 
+FDisk::FDisk(const FPoint3& pos, const FVector3& nrm, Float r) : position(pos), normal(Normalize(nrm)), radius(r)
+{
+	// CalcWorldBounds shape.h:238-251: the square spanned by the frame's binormal / tangent (FFrame(normal) -> SetFromZ,
+	// geometry.h:344-348, 372-377: n is normalised once more, t = Normalize(Cross(n, tmp_s)), s = Normalize(Cross(t, n)))
+	const FVector3 n = Normalize(normal);
+	const FVector3 tmp_s = (std::abs(n.x) > 0.99f) ? FVector3(0, 1, 0) : FVector3(1, 0, 0);
+	const FVector3 t = Normalize(Cross(n, tmp_s));
+	const FVector3 s = Normalize(Cross(t, n));
+	const FVector3 rb = s * radius, rt = t * radius;
+	FBounds3 bbox(position + rb + rt, position + rb + rt);
+	bbox = bbox.Join(position + rb - rt);
+	bbox = bbox.Join(position - rb - rt);
+	bbox = bbox.Join(position - rb + rt);
+	tightBox = bbox;
+	bbox.CheckThinness();
+	worldBox = bbox;
+}
+
 // ---- OBJ ingest: own reader, the reference's vertex transform (shape.cc:23-68) ------------------------------
 bool LoadTriangleMesh(const char* filename, std::vector<std::shared_ptr<FTriangle>>& out, bool flip_normal, bool bFlipHandedness, const FVector3& offset, Float inScale)
 {
@@ -261,6 +279,7 @@ bool FlattenScene(const FScene& scene, FlatScene& out, std::string* error)
 			int kind = P.shape->Kind(), idx = 0;
 			if (kind == JP_SHAPE_TRIANGLE) { const FTriangle* t = static_cast<const FTriangle*>(P.shape); idx = (int)out.tri_p0.size() / 3; push3(out.tri_p0, t->p0); push3(out.tri_p1, t->p1); push3(out.tri_p2, t->p2); push3(out.tri_n, t->normal); }
 			else if (kind == JP_SHAPE_RECTANGLE) { const FRectangle* r = static_cast<const FRectangle*>(P.shape); idx = (int)out.rect_p0.size() / 3; push3(out.rect_p0, r->p0); push3(out.rect_p1, r->p1); push3(out.rect_p2, r->p2); push3(out.rect_p3, r->p3); push3(out.rect_n, r->normal); }
+			else if (kind == JP_SHAPE_DISK) { const FDisk* k = static_cast<const FDisk*>(P.shape); idx = (int)out.disk_radius.size(); push3(out.disk_center, k->position); push3(out.disk_normal, k->normal); out.disk_radius.push_back(k->radius); }
 			else { const FSphere* s = static_cast<const FSphere*>(P.shape); idx = (int)out.sph_radius.size(); push3(out.sph_center, s->center); out.sph_radius.push_back(s->radius); }
 			it = shapeRef.insert(std::make_pair(P.shape, std::make_pair(kind, idx))).first;
 		}
@@ -303,6 +322,7 @@ bool FlattenScene(const FScene& scene, FlatScene& out, std::string* error)
 	v.n_triangles = (int)out.tri_p0.size() / 3; v.tri_p0 = out.tri_p0.data(); v.tri_p1 = out.tri_p1.data(); v.tri_p2 = out.tri_p2.data(); v.tri_n = out.tri_n.data();
 	v.n_rectangles = (int)out.rect_p0.size() / 3; v.rect_p0 = out.rect_p0.data(); v.rect_p1 = out.rect_p1.data(); v.rect_p2 = out.rect_p2.data(); v.rect_p3 = out.rect_p3.data(); v.rect_n = out.rect_n.data();
 	v.n_spheres = (int)out.sph_radius.size(); v.sph_center = out.sph_center.data(); v.sph_radius = out.sph_radius.data();
+	v.n_disks = (int)out.disk_radius.size(); v.disk_center = out.disk_center.data(); v.disk_normal = out.disk_normal.data(); v.disk_radius = out.disk_radius.data();
 	v.n_primitives = (int)out.prim_shape_type.size(); v.prim_shape_type = out.prim_shape_type.data(); v.prim_shape_index = out.prim_shape_index.data();
 	v.prim_material = out.prim_material.data(); v.prim_light = out.prim_light.data();
 	v.n_materials = (int)out.mat_type.size(); v.mat_type = out.mat_type.data(); v.mat_params = out.mat_params.data();

@@ -223,6 +223,11 @@ class HostBackend:
         r, _r = _fa(radiance) if radiance is not None else (None, None)
         self._f("scene_sphere")(self.h, cc, C.c_float(radius), mat, r)
 
+    def disk(self, pos, normal, radius, mat=-1, radiance=None):
+        pp, _p = _fa(pos); nn, _n = _fa(normal)
+        r, _r = _fa(radiance) if radiance is not None else (None, None)
+        self._f("scene_disk")(self.h, pp, nn, C.c_float(radius), mat, r)
+
     def preprocess(self):
         self._f("scene_preprocess")(self.h)
 
@@ -335,6 +340,21 @@ def build_lights(be, width, height):
         b.pointlight((278, 273, -200), (630000.0 * 0.2, 650000.0 * 0.2, 650000.0 * 0.2))
         b.dirlight((0.3, -1.0, -0.6), (1.5, 1.2, 0.9))
     return build_cornell(be, width, height, lambert_only=False, extras=extras, env=(0.02, 0.02, 0.05))
+
+
+def build_disks(be, width, height):
+    """Cornell box with FDisk shapes (shape.h:189-275; no configuration of main.cc creates one): a disk area light below the
+    ceiling, tilted matte / metal / glass disks as occluders, a disk parallel to an axis-aligned wall, a tiny and a large one."""
+    def extras(b, m):
+        b.disk((278, 540, -279.5), (0.0, -1.0, 0.0), 60.0, m["white"], (17.0, 12.0, 4.0))       # a second, round light, facing down
+        b.disk((150, 120, -200), (0.3, 0.8, 0.5), 70.0, m["white"], None)
+        metal = b.mat_metal((0.2, 0.9, 1.1), (3.9, 2.4, 2.2), 0.15, 0.3, False)
+        b.disk((400, 200, -350), (-0.6, 0.5, 0.7), 90.0, metal, None)
+        glass = b.mat_glass(1.5, (0.98, 0.98, 0.98), (0.98, 0.98, 0.98))
+        b.disk((278, 300, -150), (0.1, 0.2, 1.0), 55.0, glass, None)
+        b.disk((1.0, 274, -280), (1.0, 0.0, 0.0), 100.0, m["white"], None)                        # just in front of the left wall
+        b.disk((300, 1.5, -100), (0.0, 1.0, 0.0), 3.0, metal, None)
+    return build_cornell(be, width, height, lambert_only=False, extras=extras, env=(0.03, 0.03, 0.03))
 
 
 def export_reference_layout(root, n_lon=187, n_lat=188):

@@ -135,6 +135,18 @@ struct Draw
 // ---------------------------------------------------------------------------------------------
 struct Tri { V3 p0, p1, p2, n; };
 struct Rect { V3 p0, p1, p2, p3, n; };
+struct Frame { V3 s, t, n; };
+inline Frame frame_from_z(V3 nn)                                         // geometry.h:345-349, 371-376
+{
+	Frame f; f.n = normalize(nn);
+	V3 tmp = (std::abs(f.n.x) > 0.99f) ? mk(0, 1, 0) : mk(1, 0, 0);
+	f.t = normalize(cross(f.n, tmp));
+	f.s = normalize(cross(f.t, f.n));
+	return f;
+}
+inline V3 to_local(const Frame& f, V3 w) { return mk(dot(f.s, w), dot(f.t, w), dot(f.n, w)); }       // geometry.h:352-358
+inline V3 to_world(const Frame& f, V3 l) { return f.s * l.x + f.t * l.y + f.n * l.z; }               // geometry.h:360-366
+struct Disk { V3 c, n; float r; };                                       // FDisk shape.h:189-275 (n normalised by the ctor)
 struct Sph { V3 c; float r; };
 
 // FTriangle::Intersect shape.h:291-327
@@ -207,6 +219,26 @@ inline bool sph_intersect(const Sph& S, const Ray& ray, Isect& is)
 	return false;
 }
 
+// FDisk::Intersect shape.h:200-221; isEqual pbrt.h:97-104 with epsilon = numeric_limits<float>::epsilon()
+inline bool disk_intersect(const Disk& D, const Ray& ray, Isect& is)
+{
+	const float dn = dot(ray.d, D.n);
+	if (std::abs(dn - 0.f) <= std::numeric_limits<float>::epsilon() * smax(1.f, smax(std::abs(dn), std::abs(0.f)))) return false;
+	const V3 op = D.c - ray.o;
+	const float distance = dot(D.n, op) / dot(D.n, ray.d);
+	if ((distance > ray.tmin) && (distance < ray.tmax))
+	{
+		const V3 hp = ray.o + distance * ray.d;
+		if (len(D.c - hp) <= D.r)
+		{
+			ray.tmax = distance;
+			is.p = hp; is.n = D.n; is.wo = -ray.d;
+			return true;
+		}
+	}
+	return false;
+}
+
 struct Box { V3 mn, mx; };
 inline Box empty_box()                                                  // geometry.h:249-256
 { const float lo = std::numeric_limits<float>::lowest(), hi = std::numeric_limits<float>::max(); Box b = { mk(hi, hi, hi), mk(lo, lo, lo) }; return b; }
@@ -268,7 +300,7 @@ struct Node { Box box; int left, right; int first, count; bool leaf; };
 struct Scene
 {
 	const JpScene* js;
-	std::vector<Tri> tris; std::vector<Rect> rects; std::vector<Sph> sphs;
+	std::vector<Tri> tris; std::vector<Rect> rects; std::vector<Sph> sphs; std::vector<Disk> disks;
 	std::vector<Box> primBox;
 	std::vector<int> order;       // primitive ids in BVH order (the re-sorted shadow_primitives)
 	std::vector<Node> nodes; int root;
@@ -280,6 +312,12 @@ struct Scene
 		int t = js->prim_shape_type[prim], i = js->prim_shape_index[prim];
 		if (t == JP_SHAPE_TRIANGLE) { Box b = box2(tris[i].p0, tris[i].p1); b = join(b, tris[i].p2); thin(b); return b; }             // shape.h:342-349
 		if (t == JP_SHAPE_RECTANGLE) { Box b = join(join(box2(rects[i].p0, rects[i].p1), rects[i].p2), rects[i].p3); thin(b); return b; } // shape.h:448-454
+		if (t == JP_SHAPE_DISK)                                                                                                       // shape.h:238-251
+		{
+			const Disk& D = disks[i]; Frame fr = frame_from_z(D.n);
+			V3 rb = fr.s * D.r, rt = fr.t * D.r;
+			Box b = box2(D.c + rb + rt, D.c + rb + rt); b = join(b, D.c + rb - rt); b = join(b, D.c - rb - rt); b = join(b, D.c - rb + rt); thin(b); return b;
+		}
 		V3 half = mk(sphs[i].r, sphs[i].r, sphs[i].r); return box2(sphs[i].c + half, sphs[i].c - half);                                // shape.h:540-544
 	}
 
@@ -326,6 +364,7 @@ struct Scene
 		for (int i = 0; i < s->n_triangles; i++) { Tri t = { ld3(s->tri_p0 + 3 * i), ld3(s->tri_p1 + 3 * i), ld3(s->tri_p2 + 3 * i), ld3(s->tri_n + 3 * i) }; tris.push_back(t); }
 		for (int i = 0; i < s->n_rectangles; i++) { Rect r = { ld3(s->rect_p0 + 3 * i), ld3(s->rect_p1 + 3 * i), ld3(s->rect_p2 + 3 * i), ld3(s->rect_p3 + 3 * i), ld3(s->rect_n + 3 * i) }; rects.push_back(r); }
 		for (int i = 0; i < s->n_spheres; i++) { Sph q = { ld3(s->sph_center + 3 * i), s->sph_radius[i] }; sphs.push_back(q); }
+		for (int i = 0; i < s->n_disks; i++) { Disk q = { ld3(s->disk_center + 3 * i), ld3(s->disk_normal + 3 * i), s->disk_radius[i] }; disks.push_back(q); }
 		for (int i = 0; i < s->n_primitives; i++) { primBox.push_back(shape_bounds(i)); order.push_back(i); }
 		for (int i = 0; i < s->n_lights; i++) if (s->light_type[i] == JP_LIGHT_ENVIRONMENT) infiniteLights.push_back(i);
 		if (s->n_primitives > 0) root = build(0, (size_t)s->n_primitives);                                  // scene.cc:20-22
@@ -334,7 +373,8 @@ struct Scene
 	bool prim_intersect(int prim, const Ray& ray, Isect& is) const     // FPrimitive::Intersect primitive.h:39-48
 	{
 		int t = js->prim_shape_type[prim], i = js->prim_shape_index[prim];
-		bool hit = t == JP_SHAPE_TRIANGLE ? tri_intersect(tris[i], ray, is) : (t == JP_SHAPE_RECTANGLE ? rect_intersect(rects[i], ray, is) : sph_intersect(sphs[i], ray, is));
+		bool hit = t == JP_SHAPE_TRIANGLE ? tri_intersect(tris[i], ray, is) : (t == JP_SHAPE_RECTANGLE ? rect_intersect(rects[i], ray, is)
+		           : (t == JP_SHAPE_DISK ? disk_intersect(disks[i], ray, is) : sph_intersect(sphs[i], ray, is)));
 		if (hit) is.prim = prim;
 		return hit;
 	}
@@ -386,17 +426,6 @@ inline V3 uniform_sphere(float ux, float uy)                             // samp
 // ---------------------------------------------------------------------------------------------
 // frame + BSDFs (geometry.h:326-378, bsdf.h, bsdf.cc, microfacet.cc, material.h/.cc)
 // ---------------------------------------------------------------------------------------------
-struct Frame { V3 s, t, n; };
-inline Frame frame_from_z(V3 nn)                                         // geometry.h:345-349, 371-376
-{
-	Frame f; f.n = normalize(nn);
-	V3 tmp = (std::abs(f.n.x) > 0.99f) ? mk(0, 1, 0) : mk(1, 0, 0);
-	f.t = normalize(cross(f.n, tmp));
-	f.s = normalize(cross(f.t, f.n));
-	return f;
-}
-inline V3 to_local(const Frame& f, V3 w) { return mk(dot(f.s, w), dot(f.t, w), dot(f.n, w)); }       // geometry.h:352-358
-inline V3 to_world(const Frame& f, V3 l) { return f.s * l.x + f.t * l.y + f.n * l.z; }               // geometry.h:360-366
 
 enum { BS_REFLECTION = 1, BS_TRANSMISSION = 2, BS_SPECULAR = 4, BS_DIFFUSE = 8, BS_GLOSSY = 16 };   // bsdf.h:208-219
 enum { CL_LAMBERT, CL_MIRROR, CL_FRESNEL_SPECULAR, CL_MICROFACET };
@@ -676,6 +705,7 @@ inline float shape_area(const Scene& sc, int prim)
 	int t = sc.js->prim_shape_type[prim], i = sc.js->prim_shape_index[prim];
 	if (t == JP_SHAPE_TRIANGLE) return 0.5f * len(cross(sc.tris[i].p1 - sc.tris[i].p0, sc.tris[i].p2 - sc.tris[i].p0));     // shape.h:351
 	if (t == JP_SHAPE_RECTANGLE) return len(cross(sc.rects[i].p0 - sc.rects[i].p1, sc.rects[i].p2 - sc.rects[i].p1));       // shape.h:457
+	if (t == JP_SHAPE_DISK) return kPi * sc.disks[i].r * sc.disks[i].r;                                                     // shape.h:253
 	return 4 * kPi * (sc.sphs[i].r * sc.sphs[i].r);                                                                         // shape.h:546 (radius2 = r*r)
 }
 
@@ -693,6 +723,13 @@ inline void sample_position(const Scene& sc, int prim, float ux, float uy, V3& p
 	{
 		const Rect& R = sc.rects[i];
 		pos = R.p1 + (R.p0 - R.p1) * ux + (R.p2 - R.p1) * uy; nrm = R.n;
+	}
+	else if (t == JP_SHAPE_DISK)                                              // shape.h:256-268
+	{
+		const Disk& D = sc.disks[i];
+		Frame fr = frame_from_z(D.n);
+		float px, py; concentric_disk(ux, uy, px, py);
+		pos = D.c + D.r * (fr.s * px + fr.t * py); nrm = D.n;
 	}
 	else
 	{

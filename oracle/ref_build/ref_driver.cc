@@ -197,6 +197,13 @@ void ref_scene_sphere(void* h, const float* center, float radius, int mat, const
 	attach(rs, shape, mat, radiance);
 }
 
+void ref_scene_disk(void* h, const float* pos, const float* normal, float radius, int mat, const float* radiance)
+{
+	RefScene* rs = (RefScene*)h;
+	std::shared_ptr<FShape> shape = rs->scene->CreateShape<FDisk>(V3(pos), V3(normal), radius);   // shape.h:192
+	attach(rs, shape, mat, radiance);
+}
+
 void ref_scene_preprocess(void* h)
 {
 	RefScene* rs = (RefScene*)h;

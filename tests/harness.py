@@ -70,6 +70,7 @@ def ref_lib():
         L.ref_scene_mesh.argtypes = [_vp, C.c_char_p, C.c_int, C.c_int, _fp, C.c_float, C.c_int, _fp]
         L.ref_scene_rect.argtypes = [_vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _fp]
         L.ref_scene_sphere.argtypes = [_vp, _fp, C.c_float, C.c_int, _fp]
+        L.ref_scene_disk.argtypes = [_vp, _fp, _fp, C.c_float, C.c_int, _fp]
         L.ref_scene_preprocess.argtypes = [_vp]
         L.ref_num_primitives.argtypes = [_vp]
         L.ref_num_lights.argtypes = [_vp]
@@ -139,6 +140,7 @@ SCENES = {
     "bunny_small": lambda be, W, H: scenes.build_bunny(be, W, H, obj_path=os.path.join(GOLDEN, "bunny_24x16.obj")),
     "misc": lambda be, W, H: scenes.build_misc(be, W, H),
     "lights": lambda be, W, H: scenes.build_lights(be, W, H),
+    "disks": lambda be, W, H: scenes.build_disks(be, W, H),
 }
 
 

@@ -18,14 +18,14 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 TOL_L2 = 1e-4
-SCENE_NAMES = ["cornell", "cornell_lambert", "bunny_small", "misc", "lights"]
+SCENE_NAMES = ["cornell", "cornell_lambert", "bunny_small", "misc", "lights", "disks"]
 
 
 def l2(a, b):
     return float(np.sqrt(((a - b) ** 2).sum(-1)).mean())
 
 
-EXACT_SCENES = ("cornell", "cornell_lambert", "misc", "lights")   # no tessellated mesh: the reference's BVH drops no hit
+EXACT_SCENES = ("cornell", "cornell_lambert", "misc", "lights", "disks")   # no tessellated mesh: the reference's BVH drops no hit
 
 
 def assert_film(gpu_ctx, film, ref, name=None, tol=TOL_L2):

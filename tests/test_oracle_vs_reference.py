@@ -10,7 +10,8 @@ pytestmark = pytest.mark.skipif(not Hm.have_ref(), reason="oracle/_ref/libjp_ref
 
 @pytest.mark.parametrize("name,W,Hh,spp,depth,seed", [
     ("cornell", 40, 30, 3, 5, 7), ("cornell_lambert", 33, 47, 2, 2, 99), ("bunny_small", 64, 40, 4, 5, 1234),
-    ("misc", 56, 56, 6, 8, 5), ("cornell", 16, 16, 32, 0, 3), ("misc", 20, 61, 5, 1, 11)])
+    ("misc", 56, 56, 6, 8, 5), ("cornell", 16, 16, 32, 0, 3), ("misc", 20, 61, 5, 1, 11), ("lights", 48, 40, 4, 5, 21),
+    ("disks", 64, 64, 8, 5, 31), ("disks", 37, 53, 3, 2, 8)])
 def test_live_reference_equality(H, name, W, Hh, spp, depth, seed):
     H.libc_srand(1)
     rb = H.SCENES[name](H.RefBackend(name), W, Hh)
