@@ -42,6 +42,10 @@ enum { JP_LIGHT_ENVIRONMENT = 0, JP_LIGHT_AREA = 1, JP_LIGHT_POINT = 2, JP_LIGHT
 /* sampler: the stock sequential mt19937_64 stream (sampler.h:16-54) cannot be reproduced by a parallel
  * device; the device path implements the counter-based stream of include/jp_counter_rng.h only. */
 enum { JP_SAMPLER_STOCK_MT19937 = 0, JP_SAMPLER_COUNTER = 1 };
+/* integrators (integrator.h): PATH = FPathIntegratorIteration (integrator.cc:316-403; FPathIntegratorRecursive is the same
+ * estimator); WHITTED = FWhittedIntegrator (integrator.cc:115-220; branches at mirrors, one thread walks a sample's whole
+ * tree); DEBUG_NORMAL = FDebugIntegrator (integrator.h:44-58).  The last two are API completeness, not the hot path. */
+enum { JP_INTEGRATOR_PATH = 0, JP_INTEGRATOR_WHITTED = 1, JP_INTEGRATOR_DEBUG_NORMAL = 2 };
 
 #define JP_MAT_PARAM_STRIDE 16
 /* mat_params layout, JP_MAT_PARAM_STRIDE floats per material (the state the reference material objects hold):
@@ -116,7 +120,7 @@ typedef struct JpRenderParams {
      * b % shard_count == shard_index.  Pixels outside the shard are written as 0, so the sum over shards
      * (one RCCL reduce) is the full film.  shard_count <= 1 renders everything. */
     int32_t band_rows, shard_index, shard_count;
-    int32_t reserved;
+    int32_t integrator;          /* JP_INTEGRATOR_*: 0 = FPathIntegratorIteration / Recursive (the hot path, wavefront kernels)   */
 } JpRenderParams;
 
 typedef struct JpCounters {

@@ -49,7 +49,7 @@ class JpScene(C.Structure):
 class JpRenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
                 ("sampler_mode", C.c_int32), ("seed", C.c_uint32),
-                ("band_rows", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("reserved", C.c_int32)]
+                ("band_rows", C.c_int32), ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("integrator", C.c_int32)]
 
 
 class JpCounters(C.Structure):
@@ -65,9 +65,12 @@ class JpBuildInfo(C.Structure):
                 ("device_build_ms", C.c_double), ("libm_sincosf", C.c_int32), ("reserved", C.c_int32)]
 
 
+JP_INTEGRATOR_PATH, JP_INTEGRATOR_WHITTED, JP_INTEGRATOR_DEBUG_NORMAL = 0, 1, 2
+
+
 def render_params(width, height, spp, max_depth=5, seed=1234, sampler_mode=JP_SAMPLER_COUNTER,
-                  band_rows=20, shard_index=0, shard_count=1):
-    return JpRenderParams(width, height, spp, max_depth, sampler_mode, seed, band_rows, shard_index, shard_count, 0)
+                  band_rows=20, shard_index=0, shard_count=1, integrator=JP_INTEGRATOR_PATH):
+    return JpRenderParams(width, height, spp, max_depth, sampler_mode, seed, band_rows, shard_index, shard_count, integrator)
 
 
 class JetPbrtError(RuntimeError):
@@ -112,6 +115,7 @@ def host_lib():
         L.jp_host_flatten.argtypes = [C.c_void_p]
         L.jp_host_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.POINTER(JpCounters)]
+        L.jp_host_render_other.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p]
         L.jp_host_save_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
         _host = L
     return _host

@@ -526,6 +526,159 @@ __global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow(SceneView sc, Queues q, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// k_other: the reference's other two integrators behind the same Render() seam, as a megakernel --
+// one thread owns one camera sample and walks it to the end; not the hot path, no queues.
+//   FWhittedIntegrator::Li integrator.cc:115-220 branches: a mirror matches SpecularReflect AND SpecularReflectAndTransmit
+//   (MatchTypes, bsdf.h:282), glass matches the latter, and the sampler draws of the second branch start where the first
+//   branch's subtree stopped -- so a sample is walked depth first by one thread with an explicit frame stack, which yields
+//   the reference's draw order and its nested products f * Li(child) * |cos| / pdf by construction.
+//   FDebugIntegrator::Li integrator.h:44-58: the hit normal as a colour.
+// The radiance goes to lacc[slot]; k_resolve sums the samples of a pixel as for the path integrator.
+// ---------------------------------------------------------------------------------------------------------------------
+#define JP_WHITTED_MAX_DEPTH 16
+struct WFrame { V3 L, p, N, wo, f; float absd, pdf, up; int mat, k; };
+
+template <int kMode>
+__global__ void __launch_bounds__(JP_BLOCK) k_other(SceneView sc, Queues q, RenderConst rc, int kind, int depth_lds, DevCounters* cnt)
+{
+	SceneAccess<kMode> acc(sc, depth_lds);
+	const unsigned int total = (unsigned int)rc.npix * rc.sbatch;
+	unsigned int n_closest = 0, n_hit = 0, n_shadow = 0, n_occ = 0;
+	for (unsigned int slot = blockIdx.x * JP_BLOCK + threadIdx.x; slot < total; slot += gridDim.x * JP_BLOCK)
+	{
+		const int pix = slot % rc.npix, s = rc.s0 + slot / rc.npix;
+		int x, y; pixel_of(rc, pix, x, y);
+		const uint32_t key = jp_rng_key(rc.seed, (uint32_t)x, (uint32_t)y, (uint32_t)s);
+		unsigned int dim = 2;
+		V3 o, d;
+		{
+			const float fx = (float)x + jp_rng_float(key, 0), fy = (float)y + jp_rng_float(key, 1);
+			const V3 front = mk(sc.cam.front[0], sc.cam.front[1], sc.cam.front[2]), right = mk(sc.cam.right[0], sc.cam.right[1], sc.cam.right[2]), up = mk(sc.cam.up[0], sc.cam.up[1], sc.cam.up[2]);
+			o = mk(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2]);
+			d = normalize(front + right * (fx / sc.cam.res_x - 0.5f) + up * (0.5f - fy / sc.cam.res_y));
+		}
+		V3 result = mk(0, 0, 0);
+		if (kind == JP_INTEGRATOR_DEBUG_NORMAL)
+		{
+			float tmax = JP_INF; const int hit = acc.template trace<false>(sc, o, d, 0.001f, tmax);
+			n_closest++;
+			if (hit >= 0)
+			{
+				n_hit++;
+				const float4 g3 = sc.prims[4 * hit + 3]; const int type = __float_as_int(g3.w);
+				const V3 p = o + tmax * d;
+				if (type == JP_SHAPE_TRIANGLE) result = xyz(g3);
+				else if (type == JP_SHAPE_RECTANGLE) result = dot(xyz(g3), d) <= 0 ? xyz(g3) : -xyz(g3);
+				else if (type == JP_SHAPE_DISK) result = xyz(sc.prims[4 * hit + 1]);
+				else result = normalize(p - xyz(sc.prims[4 * hit]));
+			}
+			q.lacc[slot] = make_float4(result.x, result.y, result.z, 0.f);
+			continue;
+		}
+		WFrame st[JP_WHITTED_MAX_DEPTH];
+		int sp = 0;
+		V3 ret = mk(0, 0, 0);
+		bool entering = true;
+		for (;;)
+		{
+			if (entering)
+			{   // ---- Li(ray, depth = sp): intersection, emission, direct light (integrator.cc:119-158) ----
+				int hit, mat = -1; float tmax; V3 p = o, N = mk(0, 0, 1);
+				for (;;)
+				{
+					tmax = JP_INF; hit = acc.template trace<false>(sc, o, d, 0.001f, tmax);
+					n_closest++;
+					if (hit < 0) break;
+					n_hit++;
+					const float4 g3 = sc.prims[4 * hit + 3]; const int type = __float_as_int(g3.w);
+					p = o + tmax * d;
+					if (type == JP_SHAPE_TRIANGLE) N = xyz(g3);
+					else if (type == JP_SHAPE_RECTANGLE) N = dot(xyz(g3), d) <= 0 ? xyz(g3) : -xyz(g3);
+					else if (type == JP_SHAPE_DISK) N = xyz(sc.prims[4 * hit + 1]);
+					else N = normalize(p - xyz(sc.prims[4 * hit]));
+					mat = sc.meta[hit].y;
+					if (mat >= 0) break;
+					o = p;                                                            // nullptr material: same direction, same depth (integrator.cc:137-139)
+				}
+				if (hit < 0) { ret = sc.n_env > 0 ? mk(sc.env_sum.x, sc.env_sum.y, sc.env_sum.z) : mk(0, 0, 0); entering = false; continue; }   // integrator.cc:123-128
+				const int mtype = sc.mat_type[mat];
+				float up = 0.f; if (mtype == JP_MAT_PLASTIC) up = jp_rng_float(key, dim++);
+				Closure c; make_closure(sc.mats, mtype, mat, up, c);
+				const Frame fr = frame_from_z(N);
+				const V3 wo_w = -d, wo = to_local(fr, wo_w);
+				V3 L = mk(0, 0, 0);
+				{
+					const int li = sc.meta[hit].z;
+					V3 Le = mk(0, 0, 0);
+					if (li >= 0 && dot(N, wo_w) > 0.f) Le = xyz(sc.lights[2 * li]);
+					L = L + Le;                                                       // integrator.cc:142
+				}
+				for (int li = 0; li < sc.n_lights; li++)                              // integrator.cc:145-158
+				{
+					const float ux = jp_rng_float(key, dim), uy = jp_rng_float(key, dim + 1); dim += 2;
+					const float4 lrad = sc.lights[2 * li];
+					LightSample ls = sample_li(sc, sc.prims, sc.lights, li, p, N, ux, uy);
+					if (isblack(ls.Li) || ls.pdf == 0.f) continue;
+					const V3 f = eval_local(c, wo, to_local(fr, ls.wi));
+					if (isblack(f)) continue;
+					const V3 sdir = __float_as_int(lrad.w) == JP_LIGHT_AREA ? ls.wi : normalize(ls.pos - p);
+					float stmax = len(p - ls.pos) - 0.001f;
+					n_shadow++;
+					if (acc.template trace<true>(sc, p, sdir, 0.001f, stmax) >= 0) { n_occ++; continue; }
+					L = L + cmul(f, ls.Li) * absdot(ls.wi, N) / ls.pdf;
+				}
+				st[sp].L = L; st[sp].p = p; st[sp].N = N; st[sp].wo = wo_w; st[sp].mat = mat; st[sp].up = up; st[sp].k = 0;
+				entering = false;
+				ret = mk(0, 0, 0);
+				// fall into the branch loop of this frame with nothing to add yet
+				st[sp].f = mk(0, 0, 0); st[sp].absd = 0.f; st[sp].pdf = 1.f;
+				goto branch;
+			}
+			// ---- a value `ret` comes back: finished sample, or the child of the frame below ----
+			if (sp == 0) { result = ret; break; }
+			sp--;
+			st[sp].L = st[sp].L + cmul(st[sp].f, ret) * st[sp].absd / st[sp].pdf;       // integrator.cc:185, 203, 220
+		branch:
+			{
+				WFrame& F = st[sp];
+				bool descended = false;
+				if (sp + 1 < rc.max_depth)                                            // integrator.cc:161
+				{
+					const int mtype = sc.mat_type[F.mat];
+					Closure c; make_closure(sc.mats, mtype, F.mat, F.up, c);
+					const int flags = c.kind == CL_LAMBERT ? (1 | 8) : c.kind == CL_MIRROR ? (1 | 4) : c.kind == CL_FRESNEL_SPECULAR ? (4 | 1 | 2) : (1 | 16);
+					while (F.k < 3)
+					{
+						const int want = F.k == 0 ? (4 | 1) : (F.k == 1 ? (4 | 2) : (4 | 1 | 2));   // SpecularReflect / Transmit / ReflectAndTransmit
+						F.k++;
+						if ((flags & want) != flags) continue;                         // MatchTypes bsdf.h:282
+						const float ux = jp_rng_float(key, dim), uy = jp_rng_float(key, dim + 1); dim += 2;
+						const Frame fr = frame_from_z(F.N);
+						BsdfSample bs = sample_local(c, to_local(fr, F.wo), ux, uy);
+						bs.wi = to_world(fr, bs.wi);
+						if (isblack(bs.f) || bs.pdf == 0.f) continue;
+						F.f = bs.f; F.absd = absdot(bs.wi, F.N); F.pdf = bs.pdf;
+						o = F.p; d = bs.wi;
+						sp++; entering = true; descended = true;
+						break;
+					}
+				}
+				if (!descended) ret = F.L;                                            // integrator.cc:169: this frame is done
+			}
+		}
+		q.lacc[slot] = make_float4(result.x, result.y, result.z, 0.f);
+	}
+	for (int off = 32; off > 0; off >>= 1) { n_closest += __shfl_down(n_closest, off); n_hit += __shfl_down(n_hit, off); n_shadow += __shfl_down(n_shadow, off); n_occ += __shfl_down(n_occ, off); }
+	if ((threadIdx.x & 63) == 0)
+	{
+		if (n_closest) atomicAdd(&cnt->closest, (unsigned long long)n_closest);
+		if (n_hit) atomicAdd(&cnt->closest_hit, (unsigned long long)n_hit);
+		if (n_shadow) atomicAdd(&cnt->shadow, (unsigned long long)n_shadow);
+		if (n_occ) atomicAdd(&cnt->shadow_occ, (unsigned long long)n_occ);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_resolve: the per-pixel sample loop's sum (integrator.cc:89,102-108) in sample-index order; the running sum of a
 // pixel lives in pix_acc across batches; the last batch writes Clamp01 onto the (zero) film.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1177,6 +1330,8 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 	if (!c || !rp || !film_dev) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: null argument");
 	if (!c->have_scene) return fail(JP_ERR_NO_SCENE, "jp_render: no scene uploaded");
 	if (rp->width <= 0 || rp->height <= 0 || rp->spp <= 0 || rp->max_depth < 0 || rp->max_depth > 200) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: bad width/height/spp/max_depth");
+	if (rp->integrator < JP_INTEGRATOR_PATH || rp->integrator > JP_INTEGRATOR_DEBUG_NORMAL) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: unknown integrator");
+	if (rp->integrator == JP_INTEGRATOR_WHITTED && rp->max_depth > JP_WHITTED_MAX_DEPTH) return fail(JP_ERR_UNSUPPORTED, "jp_render: the Whitted integrator supports max_depth <= 16");
 	if (rp->sampler_mode != JP_SAMPLER_COUNTER) return fail(JP_ERR_UNSUPPORTED, "jp_render: the device path implements the counter sampler only (the sequential mt19937_64 stream is not reproducible in parallel)");
 	const int band = rp->band_rows > 0 ? rp->band_rows : 20;
 	const int scount = rp->shard_count > 1 ? rp->shard_count : 1;
@@ -1226,13 +1381,23 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 		{
 			rc.s0 = s0; rc.sbatch = std::min(sbatch, rp->spp - s0);
 			{ Stamper t(c, CLS_OTHER); hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(JP_BLOCK), 0, c->stream, c->sv, c->q, rc, c->d_cnt); }
+			if (rp->integrator != JP_INTEGRATOR_PATH)
+			{   // the other two integrators: one megakernel launch per batch (k_other), then the same per-pixel sum
+				Stamper t(c, CLS_OTHER);
+				const int ogrid = (int)std::min<unsigned int>((P + JP_BLOCK - 1) / JP_BLOCK, (unsigned int)(c->n_cus * 16));
+				const size_t stack_lds = (size_t)c->stack_depth * JP_BLOCK * sizeof(int);
+				if (c->trav_mode == 5) hipLaunchKernelGGL(k_other<5>, dim3(ogrid), dim3(JP_BLOCK), stack_lds, c->stream, c->sv, c->q, rc, rp->integrator, c->stack_depth, c->d_cnt);
+				else if (c->trav_mode == 2) hipLaunchKernelGGL(k_other<2>, dim3(ogrid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, rp->integrator, c->stack_depth, c->d_cnt);
+				else if (c->trav_mode == 1) hipLaunchKernelGGL(k_other<1>, dim3(ogrid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, rp->integrator, c->stack_depth, c->d_cnt);
+				else hipLaunchKernelGGL(k_other<0>, dim3(ogrid), dim3(JP_BLOCK), stack_lds, c->stream, c->sv, c->q, rc, rp->integrator, c->stack_depth, c->d_cnt);
+			}
 			int cur = 0;
-			int iters = rp->max_depth + 1;
+			int iters = rp->integrator != JP_INTEGRATOR_PATH ? 0 : rp->max_depth + 1;
 			for (int it = 0;; it++)
 			{
 				if (it >= iters)
 				{
-					if (!c->has_null_material || it > iters + 64) break;
+					if (rp->integrator != JP_INTEGRATOR_PATH || !c->has_null_material || it > iters + 64) break;
 					// null-material primitives re-queue a path without consuming a bounce (integrator.cc:349-353): ask the device
 					DevCounters h; HIP_TRY(hipMemcpyAsync(&h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream));
 					if (h.n_queue[cur] == 0) break;
@@ -1317,7 +1482,7 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 	int L = 2;                                                   // lanes: 2 by default, JETPBRT_LANES = 1 .. 4
 	bool forced = false;
 	if (const char* e = getenv("JETPBRT_LANES")) { int v = atoi(e); if (v >= 1 && v <= 4) { L = v; forced = true; } }
-	if (c->is_lane || !c->have_scene || c->has_null_material || rp->width <= 0 || rp->height <= 0) L = 1;
+	if (c->is_lane || !c->have_scene || c->has_null_material || rp->width <= 0 || rp->height <= 0 || rp->integrator != JP_INTEGRATOR_PATH) L = 1;
 	const int band = rp->band_rows > 0 ? rp->band_rows : 20;
 	const int scount = rp->shard_count > 1 ? rp->shard_count : 1;
 	const int sidx = scount > 1 ? rp->shard_index : 0;

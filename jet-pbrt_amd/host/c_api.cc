@@ -102,6 +102,20 @@ int jp_host_render(void* h, int W, int H, int spp, int maxdepth, unsigned seed, 
 	return JP_OK;
 }
 
+// FWhittedIntegrator(maxdepth) (kind 1) / FDebugIntegrator (kind 2) .Render(scene, FCounterSampler(spp, seed), film, numthreads)
+int jp_host_render_other(void* h, int kind, int W, int H, int spp, int maxdepth, unsigned seed, int device, float* film_out)
+{
+	HostScene* hs = (HostScene*)h;
+	std::unique_ptr<FGpuPathIntegrator> integ;
+	if (kind == JP_INTEGRATOR_WHITTED) integ.reset(new FWhittedIntegrator(maxdepth, device)); else integ.reset(new FDebugIntegrator(device));
+	FFilm film(W, H);
+	FCounterSampler sampler(spp, seed);
+	integ->Render(hs->scene.get(), &sampler, &film, 16);
+	if (integ->LastStatus() != JP_OK) return integ->LastStatus();
+	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const FColor& c = film(x, y); float* o = film_out + 3 * ((size_t)y * W + x); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
+	return JP_OK;
+}
+
 // FFilm::SaveAsImage on an rgb buffer (type 0 PPM, 1 BMP, 2 HDR): returns 1 on success
 int jp_host_save_image(const float* rgb, int W, int H, const char* filename, int type)
 {

@@ -87,7 +87,7 @@ void FGpuPathIntegrator::Render(const FScene* scene, FSampler* sampler, FFilm* f
 	rp.width = film->Width(); rp.height = film->Height();
 	rp.spp = sampler->GetSamplesPerPixel(); rp.max_depth = maxDepth;
 	rp.sampler_mode = JP_SAMPLER_COUNTER; rp.seed = sampler->Seed();
-	rp.band_rows = bandRows; rp.shard_index = shardIndex; rp.shard_count = shardCount;
+	rp.band_rows = bandRows; rp.shard_index = shardIndex; rp.shard_count = shardCount; rp.integrator = kind;
 	std::vector<float> rgb((size_t)rp.width * rp.height * 3);
 	lastStatus = api.render(ctx, &rp, rgb.data());
 	if (lastStatus != JP_OK) { fprintf(stderr, "FGpuPathIntegrator::Render: %s\n", api.last_error()); return; }

@@ -321,7 +321,14 @@ protected:
 	mutable const FScene* uploaded = nullptr;
 	mutable int lastStatus = 0;
 	mutable JpCounters counters;
+protected:
+	int kind = JP_INTEGRATOR_PATH;                               // JpRenderParams::integrator
 };
+// the reference's other integrators behind the same Render() (integrator.h:44-85): device megakernel k_other, not the hot path
+class FWhittedIntegrator : public FGpuPathIntegrator
+{ public: explicit FWhittedIntegrator(int maxDepth, int deviceId = 0) : FGpuPathIntegrator(maxDepth, deviceId) { kind = JP_INTEGRATOR_WHITTED; } };
+class FDebugIntegrator : public FGpuPathIntegrator
+{ public: explicit FDebugIntegrator(int deviceId = 0) : FGpuPathIntegrator(0, deviceId) { kind = JP_INTEGRATOR_DEBUG_NORMAL; } };
 typedef FGpuPathIntegrator FPathIntegratorIteration;             // main.cc:154 compiles unchanged
 // FPathIntegratorRecursive (integrator.h:88-106, integrator.cc:233-307) is the same estimator written recursively: the same
 // draws in the same order, emission on bounce 0 / after a specular bounce, NEE over all lights, roulette from bounce 3.  It

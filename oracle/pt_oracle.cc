@@ -921,6 +921,70 @@ V3 Li(const Scene& sc, const Ray& inRay, Draw& rnd, int maxDepth, Counts& cn)   
 	return L;
 }
 
+// FWhittedIntegrator::Li integrator.cc:115-220.  typeFlags: bsdf.h:340, 398, 460, 561; MatchTypes bsdf.h:282
+inline int closure_type_flags(const Closure& c)
+{
+	return c.kind == CL_LAMBERT ? (1 | 8) : c.kind == CL_MIRROR ? (1 | 4) : c.kind == CL_FRESNEL_SPECULAR ? (4 | 1 | 2) : (1 | 16);
+}
+V3 LiWhitted(const Scene& sc, const Ray& ray, Draw& rnd, int maxDepth, int depth, Counts& cn)
+{
+	const JpScene* js = sc.js;
+	V3 L = mk(0, 0, 0);
+	Isect is; is.prim = -1;
+	bool found = sc.intersect(ray, is);
+	cn.closest++; if (found) cn.closest_hit++;
+	if (!found)
+	{
+		for (size_t k = 0; k < sc.infiniteLights.size(); k++) L = L + ld3(js->light_radiance + 3 * sc.infiniteLights[k]);
+		return L;
+	}
+	const V3 N = is.n;
+	Closure c;
+	if (!scattering(js, js->prim_material[is.prim], is.n, rnd, c))
+		return LiWhitted(sc, mkray(is.p, ray.d), rnd, maxDepth, depth, cn);           // integrator.cc:137-139
+	{
+		int li = js->prim_light[is.prim];
+		V3 Le = (li >= 0 && dot(is.n, is.wo) > 0.f) ? ld3(js->light_radiance + 3 * li) : splat(0);
+		L = L + Le;                                                                   // integrator.cc:142
+	}
+	for (int li = 0; li < js->n_lights; li++)                                         // integrator.cc:145-158
+	{
+		float ux, uy; rnd.get2(ux, uy);
+		LightSample ls = sample_li(sc, li, is, ux, uy);
+		if (isblack(ls.Li) || ls.pdf == 0.f) continue;
+		V3 f = bsdf_eval(c, is.wo, ls.wi);
+		if (!isblack(f) && !occluded(sc, is, ls.pos, cn))
+			L = L + cmul(f, ls.Li) * absdot(ls.wi, N) / ls.pdf;
+	}
+	if (depth + 1 < maxDepth)                                                         // integrator.cc:161-167
+	{
+		const int flags = closure_type_flags(c);
+		const int want[3] = { 4 | 1, 4 | 2, 4 | 1 | 2 };                              // SpecularReflect, SpecularTransmit, SpecularReflectAndTransmit
+		for (int k = 0; k < 3; k++)
+		{
+			V3 add = splat(0);
+			if ((flags & want[k]) == flags)
+			{
+				float ux, uy; rnd.get2(ux, uy);
+				BsdfSample bs = bsdf_sample(c, is.wo, ux, uy);
+				if (!(isblack(bs.f) || bs.pdf == 0.f))
+					add = cmul(bs.f, LiWhitted(sc, mkray(is.p, bs.wi), rnd, maxDepth, depth + 1, cn)) * absdot(bs.wi, is.n) / bs.pdf;
+			}
+			L = L + add;
+		}
+	}
+	return L;
+}
+
+// FDebugIntegrator::Li integrator.h:44-58: the hit normal as a colour
+V3 LiDebug(const Scene& sc, const Ray& ray, Counts& cn)
+{
+	Isect is; is.prim = -1;
+	bool found = sc.intersect(ray, is);
+	cn.closest++; if (found) cn.closest_hit++;
+	return found ? is.n : mk(0, 0, 0);
+}
+
 inline Ray camera_ray(const JpCamera& c, float fx, float fy)                      // camera.h:52-58
 {
 	V3 dir = ld3(c.front) + ld3(c.right) * (fx / c.res_x - 0.5f) + ld3(c.up) * (0.5f - fy / c.res_y);
@@ -940,7 +1004,9 @@ void render_rows(const Scene& sc, const JpRenderParams& rp, Sampler& smp, int y0
 		{
 			float fx, fy; smp.camera_sample((float)x, (float)y, fx, fy);
 			Ray ray = camera_ray(sc.js->camera, fx, fy);
-			V3 dL = Li(sc, ray, rnd, rp.max_depth, cn) * ratio;
+			const V3 Ls = rp.integrator == JP_INTEGRATOR_WHITTED ? LiWhitted(sc, ray, rnd, rp.max_depth, 0, cn)
+			            : rp.integrator == JP_INTEGRATOR_DEBUG_NORMAL ? LiDebug(sc, ray, cn) : Li(sc, ray, rnd, rp.max_depth, cn);
+			V3 dL = Ls * ratio;
 			L = L + dL;
 		} while (smp.next_sample());
 		float* o = film + 3 * ((size_t)y * rp.width + x);                         // film.h:22-23, 64-68 onto a zero film

@@ -103,6 +103,18 @@ public:
 	void Band(const FScene* s, FSampler* smp, FFilmView* v) const { DoRender(s, smp, v); }
 };
 
+class FExposedWhittedIntegrator : public FWhittedIntegrator                 // integrator.h:62-85
+{
+public:
+	using FWhittedIntegrator::FWhittedIntegrator;
+	void Band(const FScene* s, FSampler* smp, FFilmView* v) const { DoRender(s, smp, v); }
+};
+class FExposedDebugIntegrator : public FDebugIntegrator                     // integrator.h:44-58
+{
+public:
+	void Band(const FScene* s, FSampler* smp, FFilmView* v) const { DoRender(s, smp, v); }
+};
+
 class FBandTask : public FTask
 {
 public:
@@ -268,6 +280,25 @@ int ref_render_recursive(void* h, int W, int H, int spp, int maxdepth, unsigned 
 	FCounterSampler sampler(spp, seed);
 	FFilmView view(&film, 0, 0, W, H);
 	integ.Band(rs->scene.get(), &sampler, &view);
+	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++)
+	{
+		const FColor& c = film(x, y);
+		float* o = film_out + 3 * ((size_t)y * W + x);
+		o[0] = c.r; o[1] = c.g; o[2] = c.b;
+	}
+	return 0;
+}
+
+// kind 1: FWhittedIntegrator(maxdepth), kind 2: FDebugIntegrator -- whole frame, serial, counter sampler
+int ref_render_other(void* h, int kind, int W, int H, int spp, int maxdepth, unsigned seed, float* film_out)
+{
+	RefScene* rs = (RefScene*)h;
+	if (!rs->preprocessed) return -1;
+	FFilm film(W, H);
+	FCounterSampler sampler(spp, seed);
+	FFilmView view(&film, 0, 0, W, H);
+	if (kind == 1) { FExposedWhittedIntegrator integ(maxdepth); integ.Band(rs->scene.get(), &sampler, &view); }
+	else { FExposedDebugIntegrator integ; integ.Band(rs->scene.get(), &sampler, &view); }
 	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++)
 	{
 		const FColor& c = film(x, y);

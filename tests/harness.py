@@ -76,6 +76,7 @@ def ref_lib():
         L.ref_num_lights.argtypes = [_vp]
         L.ref_render.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, _vp]
         L.ref_render_recursive.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, _vp]
+        L.ref_render_other.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, _vp]
         L.ref_counters_reset.argtypes = [_vp]
         L.ref_counters_get.argtypes = [_vp, _vp]
         L.ref_trace.argtypes = [_vp, C.c_int] + [_vp] * 9
@@ -109,6 +110,13 @@ class RefBackend(scenes.HostBackend):
         """the reference's FPathIntegratorRecursive (integrator.cc:233-307), counter sampler, serial"""
         film = np.zeros((H, W, 3), np.float32)
         st = self.L.ref_render_recursive(self.h, W, H, spp, maxdepth, seed, ptr(film))
+        assert st == 0
+        return film
+
+    def render_other(self, kind, W, H, spp, maxdepth=5, seed=1234):
+        """the reference's FWhittedIntegrator (kind 1) / FDebugIntegrator (kind 2), counter sampler, serial"""
+        film = np.zeros((H, W, 3), np.float32)
+        st = self.L.ref_render_other(self.h, kind, W, H, spp, maxdepth, seed, ptr(film))
         assert st == 0
         return film
 

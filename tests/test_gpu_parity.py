@@ -704,3 +704,39 @@ def test_reference_tree_full_material_benchmark_band_strictly_identical(H, gpu_c
             assert (c.closest_rays, c.closest_hits, c.shadow_rays, c.shadow_occluded) == (cnt.closest_rays, cnt.closest_hits, cnt.shadow_rays, cnt.shadow_occluded)
         else:
             assert l2(film, ref) < TOL_L2
+
+
+# ---- the reference's other integrators: device megakernel k_other --------------------------------
+@pytest.mark.parametrize("name", ["cornell", "misc", "lights", "disks", "bunny_small"])
+@pytest.mark.parametrize("kind", [1, 2])
+def test_whitted_and_debug_integrators(H, gpu_ctx, name, kind):
+    """FWhittedIntegrator (two branches at every mirror, draws depth first, nested f * Li * cos / pdf) and FDebugIntegrator on the
+    device against the oracle, which is pinned bit-exact to the compiled reference for both (test_other_integrators_live_reference)"""
+    W, Hh, spp = 56, 48, 4
+    hb, sp = _scene(H, name, W, Hh)
+    gpu_ctx.upload(sp)
+    for depth in (5, 2):
+        p = H.jp.render_params(W, Hh, spp, depth, 77, integrator=kind)
+        film = gpu_ctx.render(p)
+        c = gpu_ctx.counters()
+        ref, cnt = H.oracle_render(sp, p, 4)
+        assert np.isfinite(film).all()
+        assert_film(gpu_ctx, film, ref, name if name != "bunny_small" else None)
+        assert abs(c.closest_rays - cnt.closest_rays) <= max(4, cnt.closest_rays * 2e-4) and abs(c.shadow_rays - cnt.shadow_rays) <= max(4, cnt.shadow_rays * 2e-4)
+    if kind == 1:
+        assert film.mean() > 0.02
+
+
+def test_whitted_through_the_host_api_and_limits(H, gpu_ctx):
+    W, Hh, spp = 40, 40, 2
+    hb, sp = _scene(H, "misc", W, Hh)
+    out = np.zeros((Hh, W, 3), np.float32)
+    st = H.jp.host_lib().jp_host_render_other(hb.h, 1, W, Hh, spp, 5, 9, 0, out.ctypes.data)
+    assert st == 0
+    gpu_ctx.upload(sp)
+    direct = gpu_ctx.render(H.jp.render_params(W, Hh, spp, 5, 9, integrator=1))
+    assert np.array_equal(out.view(np.uint32), direct.view(np.uint32))
+    with pytest.raises(H.jp.JetPbrtError):
+        gpu_ctx.render(H.jp.render_params(W, Hh, spp, 17, 9, integrator=1))       # deeper than the 16-frame stack
+    with pytest.raises(H.jp.JetPbrtError):
+        gpu_ctx.render(H.jp.render_params(W, Hh, spp, 5, 9, integrator=7))

@@ -57,3 +57,20 @@ def test_random_scenes_live_reference(H, tmp_path, seed):
         fo, _ = H.oracle_render(hb.flatten(), H.jp.render_params(W, Hh, spp, 5, 77, mode), 4)
         assert np.isfinite(fr).all()
         assert np.array_equal(fr.view(np.uint32), fo.view(np.uint32)), float(np.abs(fr - fo).max())
+
+
+@pytest.mark.parametrize("name", ["cornell", "misc", "lights", "disks", "bunny_small"])
+@pytest.mark.parametrize("kind", [1, 2])
+def test_other_integrators_live_reference(H, name, kind):
+    """FWhittedIntegrator (integrator.cc:115-220: two branches at every mirror, draws in depth-first order) and
+    FDebugIntegrator (integrator.h:44-58): the restatement is bit-identical to the compiled reference"""
+    W, Hh, spp = 40, 36, 3
+    H.libc_srand(1)
+    rb = H.SCENES[name](H.RefBackend(name), W, Hh)
+    hb = H.SCENES[name](H.scenes.HostBackend(name), W, Hh)
+    for depth in (5, 2):
+        fr = rb.render_other(kind, W, Hh, spp, depth, 55)
+        H.libc_srand(1)
+        fo, _ = H.oracle_render(hb.flatten(), H.jp.render_params(W, Hh, spp, depth, 55, integrator=kind), 0)
+        assert np.isfinite(fr).all()
+        assert np.array_equal(fr.view(np.uint32), fo.view(np.uint32)), (name, kind, depth, float(np.abs(fr - fo).max()))
