@@ -1,5 +1,5 @@
 // jet-pbrt_amd/host/cli_main.cc -- the reference's command line (main.cc:113-163) on the GPU integrator:
-//     jetpbrt sceneid spp [width height] [--assets DIR] [--out NAME] [--format bmp|ppm|hdr] [--device-bvh | --reference-tree]
+//     jetpbrt sceneid spp [width height] [--assets DIR] [--out NAME] [--format bmp|ppm|hdr] [--device-bvh | --reference-tree] [--integrator path|recursive|whitted|debug]
 // sceneid 0 = Cornell box, 1 = bunny scene; spp defaults to 50, the film to 1024 x 1024, the output to
 // <scene name>_<spp>.bmp, as in the reference.  The scene scripts are the calls of main.cc:13-111; the meshes are
 // read from DIR/cornellbox/{light,floor,shortbox,tallbox,left,right}.obj and DIR/bunny/bunny.obj (the reference
@@ -70,7 +70,7 @@ static std::shared_ptr<FScene> create_bunny_scene(const FVector2& filmsize, cons
 int main(int argc, char* argv[])
 {
 	int width = 1024, height = 1024, samples_per_pixel = 50;     // main.cc:115,119
-	std::string assets = "scene", out, format = "bmp";
+	std::string assets = "scene", out, format = "bmp", integratorName = "path";
 	fprintf(stderr, "pbrt.exe  sceneid   spp\n");                 // main.cc:121
 	std::vector<const char*> pos;
 	for (int i = 1; i < argc; i++)
@@ -79,6 +79,7 @@ int main(int argc, char* argv[])
 		else if (!strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
 		else if (!strcmp(argv[i], "--format") && i + 1 < argc) format = argv[++i];
 		else if (!strcmp(argv[i], "--device-bvh")) setenv("JETPBRT_DEVICE_BVH", "1", 1);   // FScene::deviceBuild for the scenes created below
+		else if (!strcmp(argv[i], "--integrator") && i + 1 < argc) integratorName = argv[++i];
 		else if (!strcmp(argv[i], "--reference-tree")) setenv("JETPBRT_REFERENCE_TREE", "1", 1);   // FScene::referenceTree: the reference's own BVH and traversal semantics
 		else pos.push_back(argv[i]);
 	}
@@ -97,9 +98,14 @@ int main(int argc, char* argv[])
 	fprintf(stderr, "current scene: %s\n", scene->NameStr());
 	if (scene->primitives.empty()) { fprintf(stderr, "no geometry loaded from %s\n", assets.c_str()); return 2; }
 	std::shared_ptr<FSampler> sampler = std::make_shared<FRandomSampler>(samples_per_pixel);
-	FPathIntegratorIteration integrator(5);                       // main.cc:154
-	integrator.Render(scene.get(), sampler.get(), &film, 16);     // main.cc:156
-	if (integrator.LastStatus() != JP_OK) return 3;               // no GPU / no library: fail loudly, nothing is written
+	// main.cc:154 constructs FPathIntegratorIteration(5); the commented-out alternatives of main.cc:150-153 are selectable here
+	std::unique_ptr<FGpuPathIntegrator> integrator;
+	if (integratorName == "whitted") integrator.reset(new FWhittedIntegrator(5));
+	else if (integratorName == "debug") integrator.reset(new FDebugIntegrator());
+	else if (integratorName == "recursive") integrator.reset(new FPathIntegratorRecursive(5));
+	else integrator.reset(new FPathIntegratorIteration(5));
+	integrator->Render(scene.get(), sampler.get(), &film, 16);    // main.cc:156
+	if (integrator->LastStatus() != JP_OK) return 3;              // no GPU / no library: fail loudly, nothing is written
 	char fullname[512];
 	snprintf(fullname, sizeof(fullname), "%s_%d", scene->NameStr(), samples_per_pixel);
 	const std::string name = out.empty() ? fullname : out;
