@@ -84,10 +84,9 @@ def main():
     scene = be.flatten()
     ctx = jp.Context(dev)
     ctx.upload(scene)
-    # bands that deal evenly over the ranks and over the two stream lanes inside each rank (16 rows for 512 rows, N <= 16)
-    lanes = int(os.environ.get("JETPBRT_LANES", "2"))
-    band_rows = args.band_rows if args.band_rows > 0 else jp.distributed.balanced_band_rows(H, lanes * n)
-    lanes_note = ", %d stream lanes per GPU" % lanes
+    # bands that deal evenly over the ranks (16 rows for 512 rows, N <= 32); inside a rank the library splits the shard's rows
+    # over its stream lanes by itself
+    band_rows = args.band_rows if args.band_rows > 0 else jp.distributed.balanced_band_rows(H, n)
     params = jp.render_params(W, H, spp_total, 5, 1234, band_rows=band_rows, shard_index=rank, shard_count=n)
     film_dev = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if world > 1 else None
 
@@ -129,6 +128,8 @@ def main():
 
     # ---- roofline of the dominant kernel class: per-launch HIP events on the kernel stream, last timed step ----
     c = ctx.counters()                                     # counters + per-class event times of the last timed step
+    lanes = int(ctx.build_info().lanes_last_render)
+    lanes_note = ", %d stream lanes per GPU" % lanes
     ctx.set_profiling(False)
     roof = None
     if rank == 0:

@@ -143,7 +143,7 @@ typedef struct JpBuildInfo {
     int32_t libm_sincosf;        /* which build of the host libm's sinf/cosf/sincosf the device reproduces bit for bit:
                                     1 = glibc's FMA build, 2 = its build without contraction, 0 = none (own correctly
                                     rounded evaluation; films then differ from the host reference by rare path flips)  */
-    int32_t reserved;
+    int32_t lanes_last_render;   /* stream lanes the last jp_render* used (1-4; DESIGN.md "Stream lanes")                      */
 } JpBuildInfo;
 
 typedef struct JpContext JpContext;

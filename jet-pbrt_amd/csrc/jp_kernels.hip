@@ -59,6 +59,7 @@ struct RenderConst
 	int s0, sbatch;      // first sample index and sample count of this batch
 	int n_planes;        // shadow ray planes (lights that can emit)
 	int tiled;           // pixel enumeration: 16 x 4 tiles (1) or row-major (0)
+	int lane_index, lane_count, lane_rows;   // stream lanes: this launch owns the lane_rows-row groups g of the shard's rows with g % lane_count == lane_index
 };
 
 #define FLAG_BOUNCE(f) ((f) & 0xff)
@@ -80,6 +81,7 @@ __device__ __forceinline__ void pixel_of(const RenderConst& rc, int pix, int& x,
 	}
 	else { r = pix / rc.width; lx = pix - r * rc.width; }
 	x = lx;
+	if (rc.lane_count > 1) { const int m = r / rc.lane_rows; r = (rc.lane_index + m * rc.lane_count) * rc.lane_rows + (r - m * rc.lane_rows); }   // lane row -> shard row
 	const int j = r / rc.band_rows;
 	y = (rc.shard_index + j * rc.shard_count) * rc.band_rows + (r - j * rc.band_rows);
 }
@@ -1325,7 +1327,7 @@ struct Stamper
 	~Stamper() { if (!c->profiling) return; hipEventRecord(c->evpool[a + 1], c->stream); JpContext::Stamp s = { cls, a, a + 1 }; c->stamps.push_back(s); }
 };
 
-int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sync)
+int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sync, int lane_index = 0, int lane_count = 1, int lane_group = 4)
 {
 	if (!c || !rp || !film_dev) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: null argument");
 	if (!c->have_scene) return fail(JP_ERR_NO_SCENE, "jp_render: no scene uploaded");
@@ -1342,6 +1344,12 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 	const int nbands = (rp->height + band - 1) / band;
 	int local_rows = 0;
 	for (int b = sidx; b < nbands; b += scount) local_rows += std::min(band, rp->height - b * band);
+	if (lane_count > 1)
+	{   // this lane's share of the shard's rows: groups of lane_group rows dealt round-robin (only the shard's last group can be short)
+		int mine = 0;
+		for (int g0 = lane_index * lane_group; g0 < local_rows; g0 += lane_count * lane_group) mine += std::min(lane_group, local_rows - g0);
+		local_rows = mine;
+	}
 	const long long npix = (long long)local_rows * rp->width;
 
 	HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -1372,6 +1380,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 
 		RenderConst rc; rc.width = rp->width; rc.height = rp->height; rc.spp = rp->spp; rc.max_depth = rp->max_depth; rc.seed = rp->seed;
 		rc.band_rows = band; rc.shard_index = sidx; rc.shard_count = scount; rc.npix = (int)npix; rc.local_rows = local_rows; rc.n_planes = c->n_planes;
+		rc.lane_index = lane_index; rc.lane_count = lane_count; rc.lane_rows = lane_group;
 		// measured: +6 % on the 280k-triangle scene (cache reuse), -8 % on the LDS-resident Cornell box (coherent waves finish
 		// together or not at all, which unbalances the workgroups) -> tiles only when traversal goes through global memory
 		rc.tiled = (c->trav_mode == 0 && rp->width % 16 == 0 && local_rows % 4 == 0 && !getenv("JETPBRT_NO_TILES")) ? 1 : 0;
@@ -1479,25 +1488,30 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 {
 	if (!c || !rp || !film_dev) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: null argument");
 	c->last_lanes = 1;
-	int L = 2;                                                   // lanes: 2 by default, JETPBRT_LANES = 1 .. 4
-	bool forced = false;
-	if (const char* e = getenv("JETPBRT_LANES")) { int v = atoi(e); if (v >= 1 && v <= 4) { L = v; forced = true; } }
-	if (c->is_lane || !c->have_scene || c->has_null_material || rp->width <= 0 || rp->height <= 0 || rp->integrator != JP_INTEGRATOR_PATH) L = 1;
+	// lanes: the shard's rows in groups of 4 dealt round-robin to L contexts.  Default: 3 lanes when each gets >= 16 groups and
+	// full-size batches, else 2, else 1 (measured on the benchmark frame: 1 lane 2.19, 2 lanes 2.70, 3 lanes 2.82, 4 lanes 2.38
+	// Gsamples/s).  JETPBRT_LANES = 1 .. 4 forces a count, JETPBRT_LANE_ROWS the group height.
+	int forcedL = 0, group = 4;
+	if (const char* e = getenv("JETPBRT_LANES")) { int v = atoi(e); if (v >= 1 && v <= 4) forcedL = v; }
+	if (const char* e = getenv("JETPBRT_LANE_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 64) group = v; }
+	int L = 1;
 	const int band = rp->band_rows > 0 ? rp->band_rows : 20;
 	const int scount = rp->shard_count > 1 ? rp->shard_count : 1;
 	const int sidx = scount > 1 ? rp->shard_index : 0;
-	if (L > 1)
+	if (!c->is_lane && c->have_scene && !c->has_null_material && rp->width > 0 && rp->height > 0 && rp->integrator == JP_INTEGRATOR_PATH && sidx >= 0 && sidx < scount)
 	{
-		if (sidx < 0 || sidx >= scount) L = 1;
+		const int nbands = (rp->height + band - 1) / band;
+		long long rows = 0;
+		for (int b = sidx; b < nbands; b += scount) rows += std::min(band, rp->height - b * band);
+		const long long groups = (rows + group - 1) / group;
+		if (forcedL) L = (int)std::min<long long>(forcedL, std::max<long long>(1, groups));
 		else
 		{
-			const int nbands = (rp->height + band - 1) / band;
-			int mine = 0; long long rows = 0;
-			for (int b = sidx; b < nbands; b += scount) { mine++; rows += std::min(band, rp->height - b * band); }
-			if (mine < L) L = mine < 1 ? 1 : mine;                // every lane needs at least one band of this shard
 			// worth it only when each lane still gets full-size batches (2^24 slots): measured -7 % at 512 x 512 x 64 spp
-			// (half-size batches), +17 % at 1024 spp
-			while (L > 1 && !forced && rows * rp->width * (long long)rp->spp < ((long long)L << 24)) L--;
+			// (half-size batches), +17 % / +24 % at 1024 spp with two / three lanes
+			const long long samples = rows * rp->width * (long long)rp->spp;
+			if (groups >= 48 && samples >= (3ll << 24)) L = 3;
+			else if (groups >= 2 && samples >= (2ll << 24)) L = 2;
 		}
 	}
 	if (L <= 1) return render_one(c, rp, film_dev, sync);
@@ -1506,10 +1520,8 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 	int st = make_lanes(c, L - 1); if (st != JP_OK) return st;
 	const size_t n = (size_t)rp->width * rp->height * 3;
 	// workgroups per CU and lane (measured on the benchmark frame, two lanes: 2.51 Gsamples/s at 16 + 16, 2.70 at 8 + 8,
-	// 2.74 at 6 + 6, 2.60 at 4 + 4; three lanes: 2.87 at 4 + 4 + 4; a single lane is best at 16)
+	// 2.74 at 6 + 6, 2.60 at 4 + 4; three lanes: 2.83 at 5 + 5 + 5; a single lane is best at 16)
 	const int bpc_single = c->blocks_per_cu, bpc_lane = c->bpc_from_env ? c->blocks_per_cu : std::max(4, 16 / L);
-	// bands b with b % scount == sidx go round-robin to the lanes: lane k takes those with (b / scount) % L == k
-	JpRenderParams pk = *rp; pk.band_rows = band; pk.shard_count = L * scount;
 	for (int k = 1; k < L && st == JP_OK; k++)
 	{
 		JpContext* l = c->lanes[k - 1];
@@ -1517,10 +1529,9 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 		if (l->film_n < n) { if (l->d_film) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(l->d_film); } l->d_film = nullptr; l->film_n = 0; HIP_TRY(hipMalloc((void**)&l->d_film, n * sizeof(float))); l->film_n = n; c->added_valid = false; }
 		if (c->added_valid) HIP_TRY(hipStreamWaitEvent(l->stream, c->ev_added, 0));   // the previous frame's merge still reads the lane film
 		l->blocks_per_cu = bpc_lane;
-		pk.shard_index = sidx + k * scount;
-		st = render_one(l, &pk, l->d_film, false);
+		st = render_one(l, rp, l->d_film, false, k, L, group);
 	}
-	if (st == JP_OK) { c->blocks_per_cu = bpc_lane; pk.shard_index = sidx; st = render_one(c, &pk, film_dev, false); c->blocks_per_cu = bpc_single; }
+	if (st == JP_OK) { c->blocks_per_cu = bpc_lane; st = render_one(c, rp, film_dev, false, 0, L, group); c->blocks_per_cu = bpc_single; }
 	if (st != JP_OK) return st;
 	for (int k = 1; k < L; k++)
 	{
@@ -1599,7 +1610,7 @@ int jp_get_build_info(JpContext* c, JpBuildInfo* out)
 	if (!c || !out) return fail(JP_ERR_INVALID_ARGUMENT, "jp_get_build_info: null argument");
 	if (!c->have_scene) return fail(JP_ERR_NO_SCENE, "jp_get_build_info: no scene uploaded");
 	out->built_on_device = c->build_on_device ? 1 : 0; out->traversal_mode = c->trav_mode; out->bvh_nodes = c->bvh_nodes; out->bvh_height = c->bvh_height;
-	out->device_build_ms = c->build_ms; out->libm_sincosf = c->sincosf_mode;
+	out->device_build_ms = c->build_ms; out->libm_sincosf = c->sincosf_mode; out->lanes_last_render = c->last_lanes;
 	return JP_OK;
 }
 

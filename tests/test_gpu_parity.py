@@ -520,17 +520,21 @@ def test_device_built_hierarchy_bunny(H, gpu_ctx):
 def test_two_lanes_render_the_same_film_as_one(H, gpu_ctx, monkeypatch):
     """jp_render splits the shard's bands over two stream lanes (two queue sets, concurrent kernels) and merges the two
     disjoint films: bit-identical to the single-lane film, for whole frames, band shards and back-to-back renders"""
-    hb, sp = _scene(H, "misc", 96, 100)
+    hb, sp = _scene(H, "disks", 96, 100)                          # (a scene with a null-material primitive stays on one lane)
     gpu_ctx.upload(sp)
     for params in (H.jp.render_params(96, 100, 16, 5, 21), H.jp.render_params(96, 100, 8, 5, 21, band_rows=20, shard_index=1, shard_count=2),
                    H.jp.render_params(96, 100, 8, 3, 5, band_rows=7), H.jp.render_params(96, 17, 4, 5, 5)):
         monkeypatch.setenv("JETPBRT_LANES", "1")
         one = gpu_ctx.render(params); c1 = gpu_ctx.counters()
-        monkeypatch.setenv("JETPBRT_LANES", "2")                  # force the split (by default only frames with >= 2^25 samples use it)
-        two = gpu_ctx.render(params); c2 = gpu_ctx.counters()
-        again = gpu_ctx.render(params)
-        assert np.array_equal(one.view(np.uint32), two.view(np.uint32)) and np.array_equal(two.view(np.uint32), again.view(np.uint32))
-        assert (c1.samples, c1.closest_rays, c1.shadow_rays, c1.closest_hits) == (c2.samples, c2.closest_rays, c2.shadow_rays, c2.closest_hits)
+        for lanes, rows in (("2", None), ("3", None), ("4", "1"), ("3", "7")):
+            monkeypatch.setenv("JETPBRT_LANES", lanes)            # force the split (by default only large frames use it)
+            if rows: monkeypatch.setenv("JETPBRT_LANE_ROWS", rows)
+            two = gpu_ctx.render(params); c2 = gpu_ctx.counters()
+            again = gpu_ctx.render(params)
+            if rows: monkeypatch.delenv("JETPBRT_LANE_ROWS")
+            assert np.array_equal(one.view(np.uint32), two.view(np.uint32)) and np.array_equal(two.view(np.uint32), again.view(np.uint32)), (lanes, rows)
+            assert (c1.samples, c1.closest_rays, c1.shadow_rays, c1.closest_hits) == (c2.samples, c2.closest_rays, c2.shadow_rays, c2.closest_hits)
+            assert 2 <= gpu_ctx.build_info().lanes_last_render <= int(lanes)
     ref, _ = H.oracle_render(sp, H.jp.render_params(96, 100, 16, 5, 21), 4)
     assert l2(gpu_ctx.render(H.jp.render_params(96, 100, 16, 5, 21)), ref) < TOL_L2
     monkeypatch.delenv("JETPBRT_LANES")
