@@ -385,6 +385,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 		{
 			const V3 wo_w = -d;
 			wo = to_local(fr, wo_w);
+			closure_set_wo(c, wo);
 			if (wantNee)
 			{
 				for (int li = 0; li < sc.n_lights; li++)
@@ -608,6 +609,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_other(SceneView sc, Queues q, Rend
 				Closure c; make_closure(sc.mats, mtype, mat, up, c);
 				const Frame fr = frame_from_z(N);
 				const V3 wo_w = -d, wo = to_local(fr, wo_w);
+				closure_set_wo(c, wo);
 				V3 L = mk(0, 0, 0);
 				{
 					const int li = sc.meta[hit].z;
@@ -656,7 +658,9 @@ __global__ void __launch_bounds__(JP_BLOCK) k_other(SceneView sc, Queues q, Rend
 						if ((flags & want) != flags) continue;                         // MatchTypes bsdf.h:282
 						const float ux = jp_rng_float(key, dim), uy = jp_rng_float(key, dim + 1); dim += 2;
 						const Frame fr = frame_from_z(F.N);
-						BsdfSample bs = sample_local(c, to_local(fr, F.wo), ux, uy);
+						const V3 wol = to_local(fr, F.wo);
+						closure_set_wo(c, wol);
+						BsdfSample bs = sample_local(c, wol, ux, uy);
 						bs.wi = to_world(fr, bs.wi);
 						if (isblack(bs.f) || bs.pdf == 0.f) continue;
 						F.f = bs.f; F.absd = absdot(bs.wi, F.N); F.pdf = bs.pdf;

@@ -136,6 +136,7 @@ struct Closure
 	float eta_t;            // glass (eta_i = 1)
 	float ax, ay;           // TrowbridgeReitz alphas
 	int fresnel; V3 feta, fk;
+	float lam_o;            // microfacet: Lambda(wo), the same value in every Evalf / Pdf of one shading event (closure_set_wo)
 };
 __device__ __forceinline__ bool is_delta(const Closure& c) { return c.kind == CL_MIRROR || c.kind == CL_FRESNEL_SPECULAR; }
 
@@ -236,9 +237,12 @@ __device__ __forceinline__ float tr_Lambda(const Closure& c, V3 w)
 	float a2t2 = (alpha * absTan) * (alpha * absTan);
 	return (-1 + sqrtf(1.f + a2t2)) / 2;
 }
-__device__ __forceinline__ float tr_G1(const Closure& c, V3 w) { return 1 / (1 + tr_Lambda(c, w)); }
-__device__ __forceinline__ float tr_G(const Closure& c, V3 wo, V3 wi) { return 1 / (1 + tr_Lambda(c, wo) + tr_Lambda(c, wi)); }
-__device__ __forceinline__ float tr_Pdf(const Closure& c, V3 wo, V3 wh) { return tr_D(c, wh) * tr_G1(c, wo) * absdot(wo, wh) / fabsf(wo.z); }
+// the reference evaluates Lambda(wo) anew in every G / G1 of a shading event (two light samples, the BSDF sample, its pdf);
+// it is a pure function of (closure, wo), so it is computed once per event and reused: same value, ~125 instructions less per use
+__device__ __forceinline__ void closure_set_wo(Closure& c, V3 wo) { c.lam_o = c.kind == CL_MICROFACET ? tr_Lambda(c, wo) : 0.f; }
+__device__ __forceinline__ float tr_G1o(const Closure& c) { return 1 / (1 + c.lam_o); }
+__device__ __forceinline__ float tr_G(const Closure& c, V3 wi) { return 1 / (1 + c.lam_o + tr_Lambda(c, wi)); }
+__device__ __forceinline__ float tr_Pdf(const Closure& c, V3 wo, V3 wh) { return tr_D(c, wh) * tr_G1o(c) * absdot(wo, wh) / fabsf(wo.z); }
 
 // microfacet.cc:256-301; the double-precision spots of the reference (`> .9999`, unqualified sqrt/cos/sin, `> 1e10`) kept
 __device__ __forceinline__ void tr_sample11(float cosTheta, float U1, float U2, float* slope_x, float* slope_y)
@@ -301,7 +305,7 @@ __device__ __forceinline__ V3 eval_local(const Closure& c, V3 wo, V3 wi)
 		wh = normalize(wh);
 		V3 ff = (dot(wh, mk(0, 0, 1)) < 0) ? -wh : wh;
 		V3 F = fresnel_eval(c, dot(wi, ff));
-		return cmul(c.c0 * tr_D(c, wh) * tr_G(c, wo, wi), F) / (4 * cosI * cosO);
+		return cmul(c.c0 * tr_D(c, wh) * tr_G(c, wi), F) / (4 * cosI * cosO);
 	}
 	return splat(0);                                                                          // delta BSDFs
 }
