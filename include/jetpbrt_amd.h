@@ -150,6 +150,9 @@ typedef struct JpContext JpContext;
 
 const char* jp_last_error(void);
 int  jp_abi_version(void);
+/* which build of the host libm's sinf / cosf / sincosf the device will reproduce (JpBuildInfo.libm_sincosf): probes the
+ * host's libm against the library's transcription of glibc's algorithm on 200,000 arguments.  Pure host code, no GPU needed. */
+int  jp_probe_libm_sincosf(void);
 
 /* one context per process per GPU (device_id = LOCAL_RANK) */
 int  jp_create_context(int device_id, JpContext** out);

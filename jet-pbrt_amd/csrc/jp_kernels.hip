@@ -829,6 +829,7 @@ extern "C" {
 
 const char* jp_last_error(void) { return g_err.c_str(); }
 int jp_abi_version(void) { return JP_ABI_VERSION; }
+int jp_probe_libm_sincosf(void) { return probe_host_sincosf(); }
 
 int jp_create_context(int device_id, JpContext** out)
 {

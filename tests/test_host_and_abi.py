@@ -227,3 +227,11 @@ def test_reference_tree_builder_reproduces_the_reference_topology(H):
         assert n == len(kind), (n, len(kind))
         assert np.array_equal(ok[:n], np.array(kind, np.int32)) and np.array_equal(oo, np.array(order, np.int32))
         assert np.array_equal(ob[:n].view(np.uint32), np.array(boxes, np.float32).view(np.uint32))
+
+
+def test_libm_sincosf_transcription_matches_this_host(H):
+    """the device reproduces the host libm's sinf / cosf / sincosf from a transcription of glibc's algorithm (jp_shading.h
+    sincosf_libm); the library checks that transcription against the running libm on 200,000 arguments -- on this image
+    (glibc 2.35) it must match, otherwise the bit-identical film tests would silently fall back to a tolerance"""
+    lib = C.CDLL(H.jp.HIP_LIB_PATH)
+    assert lib.jp_probe_libm_sincosf() in (1, 2)
