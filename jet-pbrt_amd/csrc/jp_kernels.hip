@@ -1170,6 +1170,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 
 	// ---- no hierarchy handed over: records go up in creation order and the tree is built on the device (jp_lbvh.h) ----
 	size_t n4nodes = nodes.size(), n4prims = prims.size(), nmeta = meta.size();
+	bool dev_wide = false; int dev_n_wide = 0;
 	c->build_on_device = device_build; c->build_ms = 0.f;
 	if (device_build)
 	{
@@ -1192,6 +1193,16 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		for (int i = 0; i < s->n_primitives; i++) devPrimOf[sorted[i]] = i;
 		height = lr.height; c->build_ms = lr.build_ms;
 		n4nodes = (size_t)4 * lr.n_nodes; n4prims = (size_t)4 * s->n_primitives; nmeta = (size_t)s->n_primitives;
+		// the 8-wide tree for the shadow rays, collapsed from the binary tree on the device as well (jp_lbvh.h)
+		bool want_wide = s->n_primitives > 64;
+		if (const char* ev = getenv("JETPBRT_DEVICE_WIDE")) want_wide = atoi(ev) != 0;
+		if (want_wide)
+		{
+			WideResult wr;
+			e = lbvh_build_wide(c->stream, (const float4*)c->d_nodes, s->n_primitives, wr);
+			if (e != hipSuccess) return fail(JP_ERR_DEVICE, std::string("jp_upload_scene: device wide-tree build failed: ") + hipGetErrorString(e));
+			if (wr.d_wide) { c->d_wide = wr.d_wide; dev_wide = true; dev_n_wide = wr.n_wide; wide_height = wr.height; use_wide = true; c->build_ms += wr.build_ms; }
+		}
 	}
 	c->bvh_height = height; c->bvh_nodes = ref_sem ? s->n_bvh_nodes : (int)(n4nodes / 4);
 
@@ -1258,7 +1269,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	HIP_TRY(up(&c->d_mats, mats.data(), mats.size() * sizeof(float4)));
 	HIP_TRY(up(&c->d_mat_type, mtype.data(), mtype.size() * sizeof(int)));
 	HIP_TRY(up(&c->d_lights, lights.data(), lights.size() * sizeof(float4)));
-	if (use_wide) HIP_TRY(up(&c->d_wide, wide.data(), wide.size() * sizeof(uint32_t)));
+	if (use_wide && !dev_wide) HIP_TRY(up(&c->d_wide, wide.data(), wide.size() * sizeof(uint32_t)));
 	if (!flat.empty()) { HIP_TRY(up(&c->d_flat, flat.data(), flat.size() * sizeof(float4))); HIP_TRY(up(&c->d_flat_leaf, flat_leaf.data(), flat_leaf.size() * sizeof(int))); }
 
 	SceneView& v = c->sv;
@@ -1269,7 +1280,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.env_sum = make_float3(envsum[0], envsum[1], envsum[2]); v.n_env = nenv;
 	v.world_radius = s->world_radius; v.cam = s->camera;
 	v.flat = (const float4*)c->d_flat; v.flat_leaf = (const int*)c->d_flat_leaf; v.n_flat = (int)flat_leaf.size();
-	v.wide = (const uint4*)c->d_wide; v.n_wide = (int)(wide.size() / 20);
+	v.wide = (const uint4*)c->d_wide; v.n_wide = dev_wide ? dev_n_wide : (int)(wide.size() / 20);
 	c->stack_depth = std::max(2, height + 2);
 	size_t scene_bytes = (n4nodes + n4prims) / 4 * 5 * sizeof(float4);   // 80-byte LDS record stride
 	size_t prim_bytes = n4prims / 4 * 5 * sizeof(float4);

@@ -293,4 +293,179 @@ static hipError_t lbvh_build(hipStream_t stream, const float4* prims0, const int
 	cleanup();
 	return hipSuccess;
 }
+
+// ---- 8-wide quantised tree for the any-hit (shadow) rays, built on the device from the binary tree above ------------------
+// Same node format as the host builder of jp_upload_scene (traverse_wide, jp_device.h), same greedy collapse: a wide node
+// starts from the two children of a binary node and keeps opening the inner child with the largest box while the result
+// fits 8 slots; a leaf of n primitives takes ceil(n / 3) slots.  One thread builds one wide node; the tree grows level by
+// level (breadth first), each level's threads allocating the wide indices of their inner children with one atomicAdd, so
+// a node's inner children are contiguous and in slot order, as the traversal expects.  Slots are assigned in list order:
+// the octant-ordered slots of the host builder only serve closest-hit ordering, which the shadow rays do not need.
+// A leaf chunk whose primitives lie more than 24 records behind the node's primitive base (LBVH leaves of one wide node need
+// not be neighbours in the sorted order) is wrapped in a wide node of its own.
+struct WideItem { int bnode; unsigned int widx; };     // bnode >= 0: binary node; < 0: a leaf reference to wrap
+
+__device__ __forceinline__ int wide_slots_of(int ref) { return ref >= 0 ? 1 : ((((-ref - 1) & 15) + 1) + 2) / 3; }
+__device__ __forceinline__ float wide_area(const float* b) { const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2]; return dx * dy + dy * dz + dz * dx; }
+
+__global__ void __launch_bounds__(64) k_wide_level(const float4* __restrict__ nodes, const WideItem* __restrict__ items, int n_items, uint32_t* __restrict__ wide,
+                                                   unsigned int* wide_count, WideItem* __restrict__ next, unsigned int* next_count, unsigned int max_wide, int* fail)
+{
+	const int it = blockIdx.x * 64 + threadIdx.x;
+	if (it >= n_items) return;
+	const WideItem item = items[it];
+	int ref[8]; float box[8][6]; int nch = 0;
+	auto add_children_of = [&](int b) {
+		const float4 n0 = nodes[4 * b], n1 = nodes[4 * b + 1], n2 = nodes[4 * b + 2], n3 = nodes[4 * b + 3];
+		ref[nch] = __float_as_int(n3.x); box[nch][0] = n0.x; box[nch][1] = n0.y; box[nch][2] = n0.z; box[nch][3] = n0.w; box[nch][4] = n1.x; box[nch][5] = n1.y; nch++;
+		ref[nch] = __float_as_int(n3.y); box[nch][0] = n1.z; box[nch][1] = n1.w; box[nch][2] = n2.x; box[nch][3] = n2.y; box[nch][4] = n2.z; box[nch][5] = n2.w; nch++;
+	};
+	float wrapbox[6];
+	if (item.bnode >= 0)
+	{
+		add_children_of(item.bnode);
+		for (;;)
+		{
+			int slots = 0; for (int k = 0; k < nch; k++) slots += wide_slots_of(ref[k]);
+			int best = -1; float bestA = -1.f;
+			for (int k = 0; k < nch; k++)
+				if (ref[k] >= 0)
+				{
+					const float4 n3 = nodes[4 * ref[k] + 3];
+					const int need = slots - 1 + wide_slots_of(__float_as_int(n3.x)) + wide_slots_of(__float_as_int(n3.y));
+					const float A = wide_area(box[k]);
+					if (need <= 8 && nch + 1 <= 8 && A > bestA) { bestA = A; best = k; }
+				}
+			if (best < 0) break;
+			const int b = ref[best];
+			for (int k = best; k + 1 < nch; k++) { ref[k] = ref[k + 1]; for (int a = 0; a < 6; a++) box[k][a] = box[k + 1][a]; }
+			nch--;
+			add_children_of(b);
+		}
+	}
+	else
+	{   // wrapper: the box comes with the item through the `next` array's companion (stored in the wide node slot itself beforehand)
+		ref[0] = item.bnode; nch = 1;
+		const float* wb = (const float*)&wide[(size_t)item.widx * 20];     // the parent parked the leaf's box here
+		for (int a = 0; a < 6; a++) { box[0][a] = wb[a]; wrapbox[a] = wb[a]; }
+	}
+	// primitive base: the smallest first primitive among the direct leaf children; leaves too far behind it are wrapped
+	int prim_base = 0x7fffffff;
+	for (int k = 0; k < nch; k++) if (ref[k] < 0) { const int first = (-ref[k] - 1) >> 4; if (first < prim_base) prim_base = first; }
+	bool wrap[8];
+	for (int k = 0; k < nch; k++)
+	{
+		wrap[k] = false;
+		if (ref[k] < 0 && item.bnode >= 0) { const int e = -ref[k] - 1, first = e >> 4, cnt = (e & 15) + 1; if (first - prim_base + cnt > 24) wrap[k] = true; }
+	}
+	// node box and scales
+	float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+	for (int k = 0; k < nch; k++) for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], box[k][a]); hi[a] = fmaxf(hi[a], box[k][3 + a]); }
+	int eb[3]; float sc[3];
+	for (int a = 0; a < 3; a++)
+	{
+		int e = (int)ceilf(log2f(fmaxf((hi[a] - lo[a]) / 255.f, 1e-30f)));
+		// log2f is approximate: make sure 255 steps really span the extent
+		e = max(-120, min(120, e));
+		while (e < 120 && fmaf(255.f, ldexpf(1.0f, e), lo[a]) < hi[a]) e++;
+		eb[a] = e + 127; sc[a] = ldexpf(1.0f, e);
+	}
+	// slots in list order: inner children (and wrapped leaves) first count, then leaf chunks
+	unsigned int ninner = 0; for (int k = 0; k < nch; k++) if (ref[k] >= 0 || wrap[k]) ninner++;
+	unsigned int child_base = 0;
+	if (ninner) { child_base = atomicAdd(wide_count, ninner); if (child_base + ninner > max_wide) { *fail = 1; return; } }
+	unsigned int nbase = ninner ? atomicAdd(next_count, ninner) : 0u;
+	unsigned char metaB[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ql[3][8], qh[3][8];
+	for (int sl = 0; sl < 8; sl++) for (int a = 0; a < 3; a++) { ql[a][sl] = 255; qh[a][sl] = 0; }
+	unsigned int imask = 0, rank = 0; int sl = 0;
+	auto quantise = [&](int slot, const float* b) {
+		for (int a = 0; a < 3; a++)
+		{
+			int q0 = (int)floorf((b[a] - lo[a]) / sc[a]), q1 = (int)ceilf((b[3 + a] - lo[a]) / sc[a]);
+			q0 = max(0, min(255, q0)); q1 = max(0, min(255, q1));
+			while (q0 > 0 && fmaf((float)q0, sc[a], lo[a]) > b[a]) q0--;
+			while (q1 < 255 && fmaf((float)q1, sc[a], lo[a]) < b[3 + a]) q1++;
+			if (fmaf((float)q1, sc[a], lo[a]) < b[3 + a]) *fail = 1;
+			ql[a][slot] = (unsigned char)q0; qh[a][slot] = (unsigned char)q1;
+		}
+	};
+	for (int k = 0; k < nch; k++)
+	{
+		if (ref[k] >= 0 || wrap[k])
+		{
+			if (sl >= 8) { *fail = 1; return; }
+			imask |= 1u << sl; metaB[sl] = (unsigned char)(0x20 | (24 + sl));
+			WideItem ni; ni.bnode = ref[k]; ni.widx = child_base + rank;
+			next[nbase + rank] = ni;
+			if (wrap[k]) { float* wb = (float*)&wide[(size_t)ni.widx * 20]; for (int a = 0; a < 6; a++) wb[a] = box[k][a]; }   // park the leaf's box for the wrapper
+			rank++;
+			quantise(sl, box[k]); sl++;
+		}
+		else
+		{
+			const int e = -ref[k] - 1, first = e >> 4, cnt = (e & 15) + 1;
+			for (int c0 = 0; c0 < cnt; c0 += 3)
+			{
+				if (sl >= 8) { *fail = 1; return; }
+				const int cc = min(3, cnt - c0), off = first + c0 - prim_base;
+				if (off < 0 || off + cc > 24) { *fail = 1; return; }
+				metaB[sl] = (unsigned char)((((1u << cc) - 1u) << 5) | (unsigned int)off);
+				quantise(sl, box[k]); sl++;
+			}
+		}
+	}
+	(void)wrapbox;
+	uint32_t* w = &wide[(size_t)item.widx * 20];
+	auto pack4 = [](const unsigned char* v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); };
+	w[0] = __float_as_uint(lo[0]); w[1] = __float_as_uint(lo[1]); w[2] = __float_as_uint(lo[2]);
+	w[3] = (uint32_t)eb[0] | ((uint32_t)eb[1] << 8) | ((uint32_t)eb[2] << 16) | (imask << 24);
+	w[4] = child_base; w[5] = prim_base == 0x7fffffff ? 0u : (uint32_t)prim_base; w[6] = pack4(metaB); w[7] = pack4(metaB + 4);
+	w[8] = pack4(ql[0]); w[9] = pack4(ql[0] + 4); w[10] = pack4(ql[1]); w[11] = pack4(ql[1] + 4);
+	w[12] = pack4(ql[2]); w[13] = pack4(ql[2] + 4); w[14] = pack4(qh[0]); w[15] = pack4(qh[0] + 4);
+	w[16] = pack4(qh[1]); w[17] = pack4(qh[1] + 4); w[18] = pack4(qh[2]); w[19] = pack4(qh[2] + 4);
+}
+
+struct WideResult { void* d_wide = nullptr; int n_wide = 0, height = 0; float build_ms = 0.f; };
+
+// nodes: the device binary tree of lbvh_build (root = node 0, which is always interior there).  On failure (a box that cannot
+// be quantised conservatively, index overflow) r.d_wide stays null and the caller keeps the binary tree for the shadow rays.
+static hipError_t lbvh_build_wide(hipStream_t stream, const float4* nodes, int n_prims, WideResult& r)
+{
+	r = WideResult();
+	if (n_prims < 2) return hipSuccess;
+	hipError_t e;
+	const unsigned int max_wide = (unsigned int)std::max(16, 2 * n_prims);
+	uint32_t* wide = nullptr; WideItem *fa = nullptr, *fb = nullptr; unsigned int* ctr = nullptr; int* fail = nullptr;
+	auto bail = [&](hipError_t err) { if (wide) hipFree(wide); if (fa) hipFree(fa); if (fb) hipFree(fb); if (ctr) hipFree(ctr); if (fail) hipFree(fail); return err; };
+	if ((e = hipMalloc((void**)&wide, (size_t)max_wide * 80)) != hipSuccess || (e = hipMalloc((void**)&fa, (size_t)max_wide * sizeof(WideItem))) != hipSuccess
+	    || (e = hipMalloc((void**)&fb, (size_t)max_wide * sizeof(WideItem))) != hipSuccess || (e = hipMalloc((void**)&ctr, 16)) != hipSuccess || (e = hipMalloc((void**)&fail, 16)) != hipSuccess)
+		return bail(e);
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	hipEventRecord(e0, stream);
+	hipMemsetAsync(wide, 0, (size_t)max_wide * 80, stream);
+	hipMemsetAsync(fail, 0, 16, stream);
+	const WideItem rootItem = { 0, 0u };
+	unsigned int h_ctr[2] = { 1u, 0u };                            // wide_count (root allocated), next_count
+	hipMemcpyAsync(fa, &rootItem, sizeof(rootItem), hipMemcpyHostToDevice, stream);
+	int n_items = 1, levels = 0; int h_fail = 0;
+	WideItem *cur = fa, *nxt = fb;
+	while (n_items > 0 && levels < 64)
+	{
+		hipMemcpyAsync(ctr, h_ctr, 8, hipMemcpyHostToDevice, stream);
+		hipLaunchKernelGGL(k_wide_level, dim3((n_items + 63) / 64), dim3(64), 0, stream, nodes, (const WideItem*)cur, n_items, wide, ctr, nxt, ctr + 1, max_wide, fail);
+		hipMemcpyAsync(h_ctr, ctr, 8, hipMemcpyDeviceToHost, stream);
+		hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, stream);
+		if ((e = hipStreamSynchronize(stream)) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return bail(e); }
+		levels++;
+		if (h_fail) break;
+		n_items = (int)h_ctr[1]; h_ctr[1] = 0u;
+		std::swap(cur, nxt);
+	}
+	hipEventRecord(e1, stream); hipStreamSynchronize(stream);
+	hipEventElapsedTime(&r.build_ms, e0, e1); hipEventDestroy(e0); hipEventDestroy(e1);
+	hipFree(fa); hipFree(fb); hipFree(ctr); hipFree(fail);
+	if (h_fail || levels >= 64) { hipFree(wide); return hipSuccess; }
+	r.d_wide = wide; r.n_wide = (int)h_ctr[0]; r.height = levels;
+	return hipSuccess;
+}
 #endif

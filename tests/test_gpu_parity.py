@@ -422,7 +422,7 @@ def test_device_built_hierarchy_records_and_film(H, gpu_ctx, name):
     hb, sp = _device_built(H, name, W, Hh)
     gpu_ctx.upload(sp)
     bi = gpu_ctx.build_info()
-    assert bi.built_on_device == 1 and bi.traversal_mode == 0 and bi.bvh_height >= 1 and bi.device_build_ms > 0
+    assert bi.built_on_device == 1 and bi.traversal_mode == (3 if sp.contents.n_primitives > 64 else 0) and bi.bvh_height >= 1 and bi.device_build_ms > 0
     rng = np.random.default_rng(17)
     m = 100000
     o = (rng.random((m, 3)) * [500, 500, 500] + [25, 25, -530]).astype(np.float32)
@@ -495,6 +495,13 @@ def test_device_built_hierarchy_edge_cases(H, gpu_ctx, tmp_path):
     tmin = np.full(m, 0.001, np.float32); tmax = np.where(rng.random(m) < 0.5, np.inf, rng.random(m) * 6).astype(np.float32)
     hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
     ohit, ot, oprim, onrm = _oracle_trace(H, sp, o, d, tmin, tmax)
+    assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)) and (prim == oprim).mean() > 0.9999
+    assert gpu_ctx.build_info().traversal_mode == 3               # the 8-wide shadow tree was collapsed on the device too
+    os.environ["JETPBRT_TRACE_WIDE"] = "1"                         # test hook: closest hits through the device-built wide tree
+    try:
+        hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
+    finally:
+        del os.environ["JETPBRT_TRACE_WIDE"]
     assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)) and (prim == oprim).mean() > 0.9999
     p = H.jp.render_params(64, 48, 8, 5, 3)
     ref, _ = H.oracle_render(sp, p, 8)
