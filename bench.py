@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU share (total spp = spp * gpus)")
     ap.add_argument("--full-materials", action="store_true", help="configs[2]: metal tall box instead of Lambertian-only")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-lane step behind roofline.exclusive (profiling runs: keeps rocprofv3's per-kernel averages to the timed configuration)")
     ap.add_argument("--band-rows", type=int, default=0, help="band height for sharding / lanes (0: largest height <= 20 that deals evenly)")
     ap.add_argument("--cpu-bands", type=int, default=2, help="20-row bands rendered by the CPU oracle at the full spp (parity sample)")
     args = ap.parse_args()
@@ -134,7 +135,7 @@ def main():
     # figure the contract asks for) reflects that sharing.  One extra, untimed step on ONE lane gives the same kernels' figures
     # when each has the GPU to itself -- reported next to the contract figure as roofline.exclusive.
     c1 = None
-    if lanes > 1 and "JETPBRT_LANES" not in os.environ:
+    if lanes > 1 and "JETPBRT_LANES" not in os.environ and not args.no_exclusive:
         os.environ["JETPBRT_LANES"] = "1"
         try:
             if world == 1:
