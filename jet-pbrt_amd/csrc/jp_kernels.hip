@@ -1015,12 +1015,14 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		std::vector<Item> queue; queue.push_back({ 0, 0u, 1 });
 		wide.assign(20, 0u);
 		bool ok = true;
+		std::vector<Child> ch; ch.reserve(16);                   // scratch reused across nodes (no allocation per wide node)
+		queue.reserve((size_t)s->n_bvh_nodes / 2 + 16); wide.reserve(((size_t)s->n_bvh_nodes / 2 + 16) * 20);
 		for (size_t qi = 0; qi < queue.size() && ok; qi++)
 		{
 			const Item it = queue[qi];
 			wide_height = std::max(wide_height, it.depth);
 			// gather up to 8 child slots: open the inner child with the largest box while the slots allow it
-			std::vector<Child> ch;
+			ch.clear();
 			auto add = [&](int n) {
 				float b[6]; pad_box(n, b);
 				if (s->bvh_left[n] >= 0) { Child c; c.node = n; c.first = c.cnt = c.leaf_first = c.leaf_cnt = 0; std::memcpy(c.b, b, sizeof(b)); ch.push_back(c); }
@@ -1060,16 +1062,16 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 			int slotOf[8]; bool used[8] = { false, false, false, false, false, false, false, false };
 			{
 				struct Cand { float score; int child, slot; };
-				std::vector<Cand> cands;
+				Cand cands[64]; int ncand = 0;                     // <= 8 children x 8 slots, on the stack
 				for (size_t k = 0; k < ch.size(); k++) for (int sl = 0; sl < 8; sl++)
 				{
 					float sc = 0;
 					for (int a = 0; a < 3; a++) { float cc = 0.5f * (ch[k].b[a] + ch[k].b[3 + a]) - 0.5f * (lo[a] + hi[a]); sc += ((sl >> a) & 1) ? cc : -cc; }
-					cands.push_back({ sc, (int)k, sl });
+					cands[ncand++] = { sc, (int)k, sl };
 				}
-				std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.score > y.score; });
-				std::vector<int> got(ch.size(), -1);
-				for (const Cand& cd : cands) if (got[cd.child] < 0 && !used[cd.slot]) { got[cd.child] = cd.slot; used[cd.slot] = true; }
+				std::sort(cands, cands + ncand, [](const Cand& x, const Cand& y) { return x.score > y.score; });
+				int got[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };
+				for (int ci = 0; ci < ncand; ci++) { const Cand& cd = cands[ci]; if (got[cd.child] < 0 && !used[cd.slot]) { got[cd.child] = cd.slot; used[cd.slot] = true; } }
 				for (size_t k = 0; k < ch.size(); k++) slotOf[k] = got[k];
 			}
 			// emit: inner children get consecutive wide indices in slot order; leaf chunks append their primitives

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <future>
 
 namespace jetpbrt
 {
@@ -24,13 +25,25 @@ inline float area(const B& b)
 	return 2.f * (dx * dy + dy * dz + dz * dx);
 }
 
+// Subtrees over disjoint index ranges are independent, so the top levels fork: each side of a split is built by its own
+// Builder into a private FlatBVH (sharing the read-only boxes / centroids and the index array, whose ranges are disjoint) and
+// the two results are appended left first -- the node and leaf order of the sequential depth-first build, whatever the thread
+// timing, so the tree does not depend on the number of threads.
 struct Builder
 {
-	const std::vector<B>& pb; std::vector<float> cen; std::vector<int32_t> idx; FlatBVH& out; int maxLeaf;
-	Builder(const std::vector<B>& pb, FlatBVH& out, int maxLeaf) : pb(pb), out(out), maxLeaf(maxLeaf)
+	const std::vector<B>& pb; std::vector<float>& cen; std::vector<int32_t>& idx; FlatBVH& out; int maxLeaf;
+	Builder(const std::vector<B>& pb, std::vector<float>& cen, std::vector<int32_t>& idx, FlatBVH& out, int maxLeaf) : pb(pb), cen(cen), idx(idx), out(out), maxLeaf(maxLeaf) {}
+	int append(const FlatBVH& sub)                                 // returns the index the sub-tree's root gets
 	{
-		idx.resize(pb.size()); cen.resize(pb.size() * 3);
-		for (size_t i = 0; i < pb.size(); i++) { idx[i] = (int32_t)i; for (int a = 0; a < 3; a++) cen[3 * i + a] = 0.5f * (pb[i].mn[a] + pb[i].mx[a]); }
+		const int off = (int)out.left.size(), poff = (int)out.prim_index.size();
+		out.bounds.insert(out.bounds.end(), sub.bounds.begin(), sub.bounds.end());
+		for (size_t i = 0; i < sub.left.size(); i++)
+		{
+			if (sub.left[i] < 0) { out.left.push_back(-((-sub.left[i] - 1) + poff) - 1); out.right.push_back(sub.right[i]); }
+			else { out.left.push_back(sub.left[i] + off); out.right.push_back(sub.right[i] + off); }
+		}
+		out.prim_index.insert(out.prim_index.end(), sub.prim_index.begin(), sub.prim_index.end());
+		return off;
 	}
 	int emit(const B& b)
 	{
@@ -46,7 +59,7 @@ struct Builder
 		for (int i = start; i < end; i++) out.prim_index.push_back(idx[i]);
 		out.left[node] = -first - 1; out.right[node] = end - start;
 	}
-	int build(int start, int end)
+	int build(int start, int end, int fork = 0)
 	{
 		B nb = emptyB(), cb = emptyB();
 		for (int i = start; i < end; i++) { grow(nb, pb[idx[i]]); growP(cb, &cen[3 * idx[i]]); }
@@ -99,8 +112,17 @@ struct Builder
 			mid = start + n / 2;
 			std::nth_element(idx.begin() + start, idx.begin() + mid, idx.begin() + end, [&](int32_t x, int32_t y) { return cen[3 * x + a] < cen[3 * y + a]; });
 		}
-		int l = build(start, mid);
-		int r = build(mid, end);
+		int l, r;
+		if (fork > 0 && n >= 8192)
+		{
+			FlatBVH lo, ro;
+			Builder lb(pb, cen, idx, lo, maxLeaf), rb(pb, cen, idx, ro, maxLeaf);
+			std::future<int> fl = std::async(std::launch::async, [&lb, start, mid, fork]() { return lb.build(start, mid, fork - 1); });
+			rb.build(mid, end, fork - 1);
+			fl.get();
+			l = append(lo); r = append(ro);
+		}
+		else { l = build(start, mid, fork); r = build(mid, end, fork); }
 		out.left[node] = l; out.right[node] = r;
 		return node;
 	}
@@ -117,8 +139,12 @@ void BuildBVH(const std::vector<FBounds3>& primBounds, FlatBVH& out, int maxLeaf
 		pb[i].mn[0] = primBounds[i]._min.x; pb[i].mn[1] = primBounds[i]._min.y; pb[i].mn[2] = primBounds[i]._min.z;
 		pb[i].mx[0] = primBounds[i]._max.x; pb[i].mx[1] = primBounds[i]._max.y; pb[i].mx[2] = primBounds[i]._max.z;
 	}
-	Builder b(pb, out, maxLeaf);
-	b.build(0, (int)pb.size());
+	std::vector<float> cen(pb.size() * 3); std::vector<int32_t> idx(pb.size());
+	for (size_t i = 0; i < pb.size(); i++) { idx[i] = (int32_t)i; for (int a = 0; a < 3; a++) cen[3 * i + a] = 0.5f * (pb[i].mn[a] + pb[i].mx[a]); }
+	int fork = 4;                                                  // up to 16 concurrent subtree builds
+	if (const char* e = getenv("JETPBRT_BVH_THREADS")) { int v = atoi(e); fork = v <= 1 ? 0 : (v <= 2 ? 1 : (v <= 4 ? 2 : (v <= 8 ? 3 : 4))); }
+	Builder b(pb, cen, idx, out, maxLeaf);
+	b.build(0, (int)pb.size(), fork);
 }
 
 // ---- the reference's own tree, node for node -------------------------------------------------------------------------
