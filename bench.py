@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- Msamples/s of the MI355X path-tracing integrator on BASELINE.json's headline workload.
+"""bench.py -- Msamples/s of the MI355X path-tracing integrator on BASELINE.json's workloads.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]                 (driver contract; N = 1 by default)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py --gpus 8 --scene bunny --width 1920 --height 1080 --spp 4096 --scaling strong      (configs[4] as written)
 
-A "step" is one full pass of the hot path over the workload: one frame of the synthetic Cornell-box-shaped scene
-(BASELINE.json configs[1]: 512x512, 1024 spp, Lambertian-only) rendered through the C ABI (jp_render), scene
-already resident in HBM, film download included.  At N > 1 the row bands of the film
-(the reference's FRenderTask unit, integrator.cc:53: 20 rows; here the largest height <= 20 that deals evenly, 16 rows
-for 512 rows on 2/4/8 ranks) are dealt round-robin to the ranks, each rank renders its bands into a device film that
-is zero elsewhere, and ONE RCCL reduce(sum) over xGMI assembles the film on rank 0.
-Weak scaling: the sample count grows with N (spp = 1024 * N), so every GPU traces the same number of paths as in
-the 1-GPU run.
+A "step" is one full pass of the hot path over the workload: one frame rendered through the C ABI (jp_render), scene
+already resident in HBM, film download included.  The HEADLINE workload is BASELINE.json
+configs[2] -- the reference's own Cornell scene (main.cc:27-33: metal tall box) at 512x512, 1024 spp -- timed over EXACTLY
+--steps frames after --warmup untimed ones.  At N = 1 the line also carries a `configs` object with one full sub-record per
+single-GPU configuration of BASELINE.json (configs[1] Lambertian-only Cornell, configs[2] full materials, configs[3] the
+bunny scene of main.cc:64-111 at 800x600, 2048 spp): each is timed over its own region of >= --min-seconds (default 10 s)
+and carries value, ms_per_step, roofline, cpu_baseline and l2_vs_cpu_ref.
 
-Rank 0 prints one JSON line.  Besides the contract fields it carries
+At N > 1 the row bands of the film (the reference's FRenderTask unit, integrator.cc:53: 20 rows; here the largest height
+<= 20 that deals evenly) are dealt round-robin to the ranks, each rank renders its bands into a device film that is zero
+elsewhere, and ONE RCCL reduce(sum) over xGMI assembles the film on rank 0.  --scaling weak (default): the sample count
+grows with N (spp = --spp * N), every GPU traces as many paths as in the 1-GPU run; --scaling strong: the frame is fixed.
+
+Rank 0 prints one JSON line.  Besides the contract fields:
   roofline     : dominant kernel class, algorithmic bytes per launch / HIP-event launch duration (events on the kernel
-                 stream, taken on the last step of the timed region) vs 8 TB/s HBM
-  cpu_baseline : the oracle restatement of the reference CPU path timed on this box's host cores on a bounded
-                 sample (whole 20-row bands at the full spp), which is also the parity sample (l2_vs_cpu_ref)
+                 stream, taken on the last step of the timed region) vs 8 TB/s HBM; `traffic` = rocprofv3 PMC bytes per unit
+                 (profiles/traffic_r02.json, source named in `traffic_source`) x this run's units per launch; `valu` = the
+                 vector-instruction issue roofline next to it (instructions per unit from the SQ counter passes under profiles/)
+  cpu_baseline : the unmodified reference (oracle/_ref) -- or the oracle port where that library is absent -- timed on this
+                 box's host cores on a bounded sample, at 16 threads (main.cc:156) and at min(cores, bands)
+  l2_vs_cpu_ref: parity sample.  Cornell: whole 20-row bands at the full spp against the oracle.  Bunny: the whole film at the
+                 full spp against the device's reference-tree mode (bit-identical to the oracle, checked in the same run on
+                 an oracle band at reduced spp)
 """
 import argparse
 import json
@@ -29,6 +39,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0    # wave64 instructions/ns: 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles at 2.4 GHz
 # algorithmic bytes per unit, SURVEY.md section 8d records attributed to the kernel that moves them (DESIGN.md "Roofline")
 B_EXTEND_PER_RAY = 32 + 8                     # ray read + hit record write
 B_SHADE_PER_PATH_IN = 8 + 40                  # hit record read + path state read
@@ -37,20 +48,112 @@ B_SHADE_PER_SHADOW_RAY = 48                   # shadow ray + contribution + pixe
 B_SHADOW_PER_RAY = 48                         # the same record read back
 B_PER_SEGMENT, B_PER_SHADOW, B_FILM_PER_PIXEL = 160, 96, 12
 
+# BASELINE.json configs -> (scene key, width, height, spp)
+CONFIGS = {
+    1: ("cornell_lambert", 512, 512, 1024),
+    2: ("cornell", 512, 512, 1024),
+    3: ("bunny", 800, 600, 2048),
+    4: ("bunny", 1920, 1080, 4096),
+}
+SCENE_LABEL = {
+    "cornell_lambert": "cornell_box, Lambertian-only BSDF",
+    "cornell": "cornell_box, full bsdf.cc + microfacet.cc materials (main.cc:27-33)",
+    "bunny": "bunny scene of main.cc:64-111 (4 x 69,938-triangle procedural stand-in + 2 rectangles = 279,754 primitives)",
+}
+
+
+def build_scene(scenes, backend, key, W, H):
+    if key == "bunny":
+        return scenes.build_bunny(backend, W, H)
+    return scenes.build_cornell(backend, W, H, lambert_only=(key == "cornell_lambert"))
+
+
+def load_profile_constants():
+    """rocprofv3 figures measured in an earlier profiling run and committed under profiles/ (never measured inside this run)"""
+    p = os.path.join(REPO, "profiles", "traffic_r02.json")
+    try:
+        return json.load(open(p))
+    except Exception:
+        return {}
+
+
+def roofline_record(c, c1, value, spp_total, n, lanes, scene_key, prof):
+    """roofline of the dominant kernel class from the per-launch HIP events of one profiled step (counters c), plus the same
+    kernels with the GPU to themselves (c1: one extra step on ONE stream lane) and the whole-path figure"""
+    survivors = max(0, c.closest_rays - c.samples)     # rays written by k_shade (every ray but the camera rays)
+    # (ms, launches, algorithmic bytes = SURVEY.md section 8d per-unit figure x units the class processes, units,
+    #  bytes attributed to the kernel that actually moves each record -- DESIGN.md section 6)
+    cls = {
+        "k_extend": (c.extend_ms, c.extend_launches, B_PER_SEGMENT * c.closest_rays, c.closest_rays, B_EXTEND_PER_RAY * c.closest_rays),
+        "k_shade": (c.shade_ms, c.shade_launches, B_PER_SEGMENT * c.closest_rays, c.closest_rays,
+                    B_SHADE_PER_PATH_IN * c.closest_rays + B_SHADE_PER_SURVIVOR * survivors + B_SHADE_PER_SHADOW_RAY * c.shadow_rays),
+        "k_shadow": (c.shadow_ms, c.shadow_launches, B_PER_SHADOW * c.shadow_rays, c.shadow_rays, B_SHADOW_PER_RAY * c.shadow_rays),
+    }
+    dom = max(cls, key=lambda k: cls[k][0])
+    ms, launches, nbytes, units, attributed = cls[dom]
+    launches = max(1, launches)
+    achieved = (nbytes / launches) / (ms / launches * 1e-3) / 1e9 if ms > 0 else 0.0
+    bytes_per_sample = (B_PER_SEGMENT * c.closest_rays + B_PER_SHADOW * c.shadow_rays) / max(1, c.samples) + B_FILM_PER_PIXEL / spp_total
+    pk = (prof.get(scene_key) or {}).get(dom) or {}
+    traffic = int(pk["hbm_bytes_per_unit"] * units / launches) if "hbm_bytes_per_unit" in pk else None
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": (pk.get("source") if traffic is not None else None),
+            "launch_ms_avg": round(ms / launches, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(nbytes / launches),
+            "unit_bytes": B_PER_SHADOW if dom == "k_shadow" else B_PER_SEGMENT, "units_per_launch": int(units / launches),
+            "attributed_bytes_per_launch": int(attributed / launches),
+            "class_ms": {k: round(v[0], 3) for k, v in cls.items()},
+            # several stream lanes: the lanes' kernels overlap, so a launch's duration includes the time it shares the
+            # GPU with the other lanes' kernels; kernel_time_over_wall is the average number of kernels in flight
+            "lanes": lanes, "kernel_time_over_wall": round((c.extend_ms + c.shade_ms + c.shadow_ms + c.other_ms) / max(1e-9, c.render_ms), 3),
+            "exclusive": None, "valu": None,
+            "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "segments_per_sample": round(c.closest_rays / max(1, c.samples), 3),
+                           "shadow_rays_per_sample": round(c.shadow_rays / max(1, c.samples), 3),
+                           "achieved_GBps": round(value * 1e6 * bytes_per_sample / 1e9, 1),
+                           "frac": round(value * 1e6 * bytes_per_sample / 1e9 / (HBM_PEAK_GBS * n), 4)}}
+    # vector-instruction issue roofline: wave64 VALU instructions per unit (rocprofv3 SQ_INSTS_VALU, profiles/) x units / time
+    src = c1 if c1 is not None else c
+    ms1 = {"k_extend": src.extend_ms, "k_shade": src.shade_ms, "k_shadow": src.shadow_ms}
+    n1 = {"k_extend": src.extend_launches, "k_shade": src.shade_launches, "k_shadow": src.shadow_launches}
+    u1 = {"k_extend": src.closest_rays, "k_shade": src.closest_rays, "k_shadow": src.shadow_rays}
+    valu = {}
+    for k in ("k_extend", "k_shade", "k_shadow"):
+        pv = (prof.get(scene_key) or {}).get(k) or {}
+        if "valu_insts_per_unit" in pv and ms1[k] > 0:
+            g = pv["valu_insts_per_unit"] * u1[k] / (ms1[k] * 1e-3) / 1e9          # wave64 instructions per ns, chip-wide
+            valu[k] = {"wave_insts_per_unit": pv["valu_insts_per_unit"], "achieved_Ginst_s": round(g, 1), "peak_Ginst_s": VALU_PEAK_GINST,
+                       "frac": round(g / VALU_PEAK_GINST, 3), "lane_utilisation": pv.get("lane_utilisation"), "source": pv.get("valu_source")}
+    if valu:
+        roof["valu"] = {"note": "wave64 VALU instructions issued per second vs 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles; kernels alone on the GPU (one stream lane)" if c1 is not None else "from the timed configuration", "kernels": valu}
+    if c1 is not None:
+        units1 = {"k_extend": B_PER_SEGMENT * c1.closest_rays, "k_shade": B_PER_SEGMENT * c1.closest_rays, "k_shadow": B_PER_SHADOW * c1.shadow_rays}
+        dom1 = max(ms1, key=lambda k: ms1[k])
+        excl = {}
+        for k in ("k_extend", "k_shade", "k_shadow"):
+            a1 = units1[k] / max(1e-9, ms1[k] * 1e-3) / 1e9
+            excl[k] = {"launch_ms_avg": round(ms1[k] / max(1, n1[k]), 4), "launches": int(n1[k]), "achieved": round(a1, 1), "frac": round(a1 / HBM_PEAK_GBS, 4)}
+        roof["exclusive"] = {"lanes": 1, "dominant": dom1, "kernels": excl}
+    return roof
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU share (total spp = spp * gpus)")
-    ap.add_argument("--full-materials", action="store_true", help="configs[2]: metal tall box instead of Lambertian-only")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")
+    ap.add_argument("--steps", type=int, default=80, help="timed frames of the headline workload (80 frames ~ 10 s on one GPU)")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", choices=sorted(SCENE_LABEL), default=None, help="headline scene (default: configs[2], cornell)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config index of the headline workload")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (weak scaling: per GPU share, total spp = spp * gpus)")
+    ap.add_argument("--full-materials", action="store_true", help="kept for round-1 command lines: same as --scene cornell")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--configs", default="1,2,3", help="sub-records at N = 1: comma list of BASELINE.json config indices, '' for none")
+    ap.add_argument("--min-seconds", type=float, default=10.0, help="length of each sub-record's timed region")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity samples")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-lane step behind roofline.exclusive (profiling runs: keeps rocprofv3's per-kernel averages to the timed configuration)")
     ap.add_argument("--band-rows", type=int, default=0, help="band height for sharding / lanes (0: largest height <= 20 that deals evenly)")
-    ap.add_argument("--cpu-bands", type=int, default=2, help="20-row bands rendered by the CPU oracle at the full spp (parity sample)")
+    ap.add_argument("--cpu-bands", type=int, default=2, help="20-row bands rendered by the CPU oracle at the full spp (Cornell parity sample)")
     args = ap.parse_args()
 
     import numpy as np
@@ -79,28 +182,13 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    W, H = args.width, args.height
-    spp_total = args.spp * n
-    be = scenes.build_cornell(scenes.HostBackend("bench"), W, H, lambert_only=not args.full_materials)
-    scene = be.flatten()
+    prof = load_profile_constants()
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     ctx = jp.Context(dev)
-    ctx.upload(scene)
-    # bands that deal evenly over the ranks (16 rows for 512 rows, N <= 32); inside a rank the library splits the shard's rows
-    # over its stream lanes by itself
-    band_rows = args.band_rows if args.band_rows > 0 else jp.distributed.balanced_band_rows(H, n)
-    params = jp.render_params(W, H, spp_total, 5, 1234, band_rows=band_rows, shard_index=rank, shard_count=n)
-    film_dev = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if world > 1 else None
-
-    def step():
-        if world == 1:
-            return ctx.render(params)                      # jp_render: kernels + film download, blocking
-        ctx.render_device(params, film_dev.data_ptr(), sync=True)
-        if backend == "nccl":
-            dist.reduce(film_dev, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI onto rank 0's film
-            return film_dev.cpu().numpy() if rank == 0 else None
-        host = film_dev.cpu()                              # rehearsal backend: the same reduce on host tensors
-        dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-        return host.numpy() if rank == 0 else None
+    Hn = None
+    if rank == 0 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        import harness as Hn                                # oracle/ bindings: the checker and the CPU baseline, never the thing measured
 
     def fence():
         ctx.synchronize()
@@ -109,146 +197,199 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    film = None
-    for i in range(args.steps):
-        if i == args.steps - 1:
-            ctx.set_profiling(True)                        # per-launch HIP events (kernel stream) on the last timed step: roofline below
-        film = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    samples_per_step = W * H * spp_total
-    value = samples_per_step * args.steps / dt / 1e6
+    def run_workload(scene_key, W, H, spp, steps, warmup, min_seconds=None, with_cpu=True, tag=""):
+        """upload, warm up, time `steps` frames (or as many as fill min_seconds), profile the last one; returns the record"""
+        spp_total = spp * n if args.scaling == "weak" else spp
+        be = build_scene(scenes, scenes.HostBackend("bench"), scene_key, W, H)
+        scene = be.flatten()
+        ctx.upload(scene)
+        band_rows = args.band_rows if args.band_rows > 0 else jp.distributed.balanced_band_rows(H, n)
+        params = jp.render_params(W, H, spp_total, 5, 1234, band_rows=band_rows, shard_index=rank, shard_count=n)
+        film_dev = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if world > 1 else None
 
-    # ---- roofline of the dominant kernel class: per-launch HIP events on the kernel stream, last timed step ----
-    c = ctx.counters()                                     # counters + per-class event times of the last timed step
-    lanes = int(ctx.build_info().lanes_last_render)
-    lanes_note = ", %d stream lanes per GPU" % lanes
-    # With several lanes a launch shares the GPU with the other lanes' kernels, so its duration (and the per-launch roofline
-    # figure the contract asks for) reflects that sharing.  One extra, untimed step on ONE lane gives the same kernels' figures
-    # when each has the GPU to itself -- reported next to the contract figure as roofline.exclusive.
-    c1 = None
-    if lanes > 1 and "JETPBRT_LANES" not in os.environ and not args.no_exclusive:
-        os.environ["JETPBRT_LANES"] = "1"
-        try:
+        def step():
             if world == 1:
-                ctx.render(params)
-            else:
-                ctx.render_device(params, film_dev.data_ptr(), sync=True)
-            c1 = ctx.counters()
-        finally:
-            del os.environ["JETPBRT_LANES"]
-    ctx.set_profiling(False)
-    roof = None
-    if rank == 0:
-        survivors = max(0, c.closest_rays - c.samples)     # rays written by k_shade (every ray but the camera rays)
-        # (ms, launches, algorithmic bytes = SURVEY.md section 8d per-unit figure x units the class processes,
-        #  bytes attributed to the kernel that actually moves each record -- DESIGN.md section 6)
-        cls = {
-            "k_extend": (c.extend_ms, c.extend_launches, B_PER_SEGMENT * c.closest_rays, B_EXTEND_PER_RAY * c.closest_rays),
-            "k_shade": (c.shade_ms, c.shade_launches, B_PER_SEGMENT * c.closest_rays,
-                        B_SHADE_PER_PATH_IN * c.closest_rays + B_SHADE_PER_SURVIVOR * survivors + B_SHADE_PER_SHADOW_RAY * c.shadow_rays),
-            "k_shadow": (c.shadow_ms, c.shadow_launches, B_PER_SHADOW * c.shadow_rays, B_SHADOW_PER_RAY * c.shadow_rays),
-        }
-        dom = max(cls, key=lambda k: cls[k][0])
-        ms, launches, nbytes, attributed = cls[dom]
-        launches = max(1, launches)
-        achieved = (nbytes / launches) / (ms / launches * 1e-3) / 1e9 if ms > 0 else 0.0
-        bytes_per_sample = (B_PER_SEGMENT * c.closest_rays + B_PER_SHADOW * c.shadow_rays) / max(1, c.samples) + B_FILM_PER_PIXEL / spp_total
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+                return ctx.render(params)                      # jp_render: kernels + film download, blocking
+            ctx.render_device(params, film_dev.data_ptr(), sync=True)
+            if backend == "nccl":
+                dist.reduce(film_dev, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI onto rank 0's film
+                return film_dev.cpu().numpy() if rank == 0 else None
+            host = film_dev.cpu()                              # rehearsal backend: the same reduce on host tensors
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            return host.numpy() if rank == 0 else None
+
+        ctx.set_profiling(False)
+        for _ in range(warmup):
+            step()
+        fence()
+        if min_seconds is not None:                           # sub-records: as many frames as fill the region (>= 3)
+            tw = time.perf_counter()
+            step()                                            # one more untimed frame, after the allocations of the first
+            fence()
+            tw = time.perf_counter() - tw
+            steps = max(3, int(min_seconds / max(1e-3, tw) + 0.999))
+        t0 = time.perf_counter()
+        film = None
+        for i in range(steps):
+            if i == steps - 1:
+                ctx.set_profiling(True)                        # per-launch HIP events (kernel stream) on the last timed step: roofline below
+            film = step()
+        fence()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        samples_per_step = W * H * spp_total
+        value = samples_per_step * steps / dt / 1e6
+        c = ctx.counters()                                     # counters + per-class event times of the last timed step
+        bi = ctx.build_info()
+        lanes = int(bi.lanes_last_render)
+        # With several lanes a launch shares the GPU with the other lanes' kernels, so its duration (and the per-launch roofline
+        # figure the contract asks for) reflects that sharing.  One extra, untimed step on ONE lane gives the same kernels' figures
+        # when each has the GPU to itself -- reported next to the contract figure as roofline.exclusive.
+        c1 = None
+        if lanes > 1 and "JETPBRT_LANES" not in os.environ and not args.no_exclusive:
+            os.environ["JETPBRT_LANES"] = "1"
             try:
-                tj = json.load(open(tpath))
-                if tj.get("kernel") == dom and tj.get("workload") == ("cornell_full" if args.full_materials else "cornell_lambert") and n == 1:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "launch_ms_avg": round(ms / launches, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(nbytes / launches),
-                "unit_bytes": B_PER_SHADOW if dom == "k_shadow" else B_PER_SEGMENT, "units_per_launch": int((c.shadow_rays if dom == "k_shadow" else c.closest_rays) / launches),
-                "attributed_bytes_per_launch": int(attributed / launches),
-                "class_ms": {k: round(v[0], 3) for k, v in cls.items()},
-                # two stream lanes: the lanes' kernels overlap, so a launch's duration includes the time it shares the
-                # GPU with the other lane's kernel; kernel_time_over_wall is the average number of kernels in flight
-                "lanes": lanes, "kernel_time_over_wall": round((c.extend_ms + c.shade_ms + c.shadow_ms + c.other_ms) / max(1e-9, c.render_ms), 3),
-                "exclusive": None,
-                "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "segments_per_sample": round(c.closest_rays / max(1, c.samples), 3),
-                               "shadow_rays_per_sample": round(c.shadow_rays / max(1, c.samples), 3),
-                               "achieved_GBps": round(value * 1e6 * bytes_per_sample / 1e9, 1),
-                               "frac": round(value * 1e6 * bytes_per_sample / 1e9 / (HBM_PEAK_GBS * n), 4)}}
+                step()
+                c1 = ctx.counters()
+            finally:
+                del os.environ["JETPBRT_LANES"]
+        ctx.set_profiling(False)
+        rec = None
+        if rank == 0:
+            rec = {"value": round(value, 2), "unit": "Msamples/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
+                   "timed_region_s": round(dt, 3),
+                   "workload": "%s, %dx%d, %d spp%s, maxDepth 5, counter sampler seed 1234" % (
+                       SCENE_LABEL[scene_key], W, H, spp_total, (" (%d per GPU share)" % spp) if (n > 1 and args.scaling == "weak") else ""),
+                   "traversal_mode": int(bi.traversal_mode), "lanes": lanes,
+                   "roofline": roofline_record(c, c1, value, spp_total, n, lanes, scene_key, prof)}
+            if with_cpu and Hn is not None and (n == 1 or os.environ.get("JETPBRT_BENCH_PARITY_ALL")):
+                rec["cpu_baseline"], rec["l2_vs_cpu_ref"] = cpu_and_parity(scene_key, scene, film, W, H, spp_total)
+            else:
+                rec["cpu_baseline"], rec["l2_vs_cpu_ref"] = None, None
+        return rec, band_rows, lanes
 
-    if rank == 0 and roof is not None and c1 is not None:
-        ms1 = {"k_extend": c1.extend_ms, "k_shade": c1.shade_ms, "k_shadow": c1.shadow_ms}
-        n1 = {"k_extend": c1.extend_launches, "k_shade": c1.shade_launches, "k_shadow": c1.shadow_launches}
-        units1 = {"k_extend": B_PER_SEGMENT * c1.closest_rays, "k_shade": B_PER_SEGMENT * c1.closest_rays, "k_shadow": B_PER_SHADOW * c1.shadow_rays}
-        dom1 = max(ms1, key=lambda k: ms1[k])
-        excl = {}
-        for k in (roof["kernel"], dom1):
-            a1 = units1[k] / max(1e-9, ms1[k] * 1e-3) / 1e9
-            excl[k] = {"launch_ms_avg": round(ms1[k] / max(1, n1[k]), 4), "launches": int(n1[k]), "achieved": round(a1, 1), "frac": round(a1 / HBM_PEAK_GBS, 4)}
-        roof["exclusive"] = {"lanes": 1, "dominant": dom1, "kernels": excl}
-
-    # ---- parity sample + CPU baseline (rank 0, N = 1 only); oracle/ is the checker here, never the thing measured ----
-    cpu = None
-    parity = None
-    if rank == 0 and not args.no_cpu and (n == 1 or os.environ.get("JETPBRT_BENCH_PARITY_ALL")):
-        sys.path.insert(0, os.path.join(REPO, "tests"))
-        import harness as Hn
-        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        threads = min(avail, 16)                           # the reference renders with 16 threads (main.cc:156)
+    def cpu_and_parity(scene_key, scene, film, W, H, spp_total):
+        """oracle/ is the checker here, never the thing measured (rank 0, N = 1)"""
         nbands = (H + 19) // 20
-        # (a) parity at the FULL spp on whole 20-row bands (bands are independent under the counter sampler)
-        k = max(1, nbands // max(1, args.cpu_bands))
-        idx = (nbands // 2) % k
-        p = jp.render_params(W, H, spp_total, 5, 1234, band_rows=20, shard_index=idx, shard_count=k)
-        ref, _ = Hn.oracle_render(scene, p, threads)
-        rows = np.zeros(H, bool)
-        for y0, y1 in jp.distributed.bands_of(H, idx, k):
-            rows[y0:y1] = True
-        d = np.sqrt(((film[rows] - ref[rows]) ** 2).sum(-1))
-        parity = {"mean_per_pixel_l2": float(d.mean()), "max_per_pixel_l2": float(d.max()), "pixels": int(d.size), "spp": spp_total,
-                  "tolerance": 1e-4, "sample": "bands b %% %d == %d of %d" % (k, idx, nbands),
-                  "bit_identical": bool(np.array_equal(film[rows].view(np.uint32), ref[rows].view(np.uint32))),
-                  "libm_sincosf": int(ctx.build_info().libm_sincosf)}
-        # (b) CPU baseline: the whole frame at a reduced spp (throughput does not depend on spp), 20-row tasks
-        cpu_spp = 64
+        t16 = min(avail, 16)                               # the reference renders with 16 threads (main.cc:156)
+        tb = min(avail, nbands)                            # one thread per 20-row task: all the parallelism the reference's decomposition has
+        bi = ctx.build_info()
+        if scene_key != "bunny":
+            # parity at the FULL spp on whole 20-row bands (bands are independent under the counter sampler)
+            k = max(1, nbands // max(1, args.cpu_bands))
+            idx = (nbands // 2) % k
+            p = jp.render_params(W, H, spp_total, 5, 1234, band_rows=20, shard_index=idx, shard_count=k)
+            ref, _ = Hn.oracle_render(scene, p, tb)
+            rows = np.zeros(H, bool)
+            for y0, y1 in jp.distributed.bands_of(H, idx, k):
+                rows[y0:y1] = True
+            d = np.sqrt(((film[rows] - ref[rows]) ** 2).sum(-1))
+            parity = {"mean_per_pixel_l2": float(d.mean()), "max_per_pixel_l2": float(d.max()), "pixels": int(d.size), "spp": spp_total,
+                      "tolerance": 1e-4, "reference": "oracle/pt_oracle.cc (pinned bit-exact to the compiled reference), counter sampler",
+                      "sample": "bands b %% %d == %d of %d" % (k, idx, nbands),
+                      "bit_identical": bool(np.array_equal(film[rows].view(np.uint32), ref[rows].view(np.uint32))),
+                      "libm_sincosf": int(bi.libm_sincosf)}
+            cpu_spp = 32
+        else:
+            # The CPU oracle needs ~40 min for this frame (SURVEY.md section 8c).  The device's reference-tree mode walks the
+            # reference's own tree with the reference's semantics and is bit-identical to the oracle (asserted here on one
+            # oracle band at reduced spp, and by tests/test_gpu_parity.py), so it serves as the full-size reference.
+            rb = scenes.HostBackend("bench_ref")
+            rb.set_reference_tree(True)
+            build_scene(scenes, rb, scene_key, W, H)
+            rscene = rb.flatten()
+            rctx = jp.Context(dev)
+            try:
+                rctx.upload(rscene)
+                t1 = time.perf_counter()
+                ref = rctx.render(jp.render_params(W, H, spp_total, 5, 1234))
+                t_ref_gpu = time.perf_counter() - t1
+                b = 17 if nbands > 17 else nbands // 2
+                low = 8
+                pb = jp.render_params(W, H, low, 5, 1234, band_rows=20, shard_index=b, shard_count=nbands)
+                gband = rctx.render(pb)
+                Hn.libc_srand(1)                            # the reference process' rand() state when it builds its tree
+                oband, _ = Hn.oracle_render(rscene, pb, tb)
+                y0, y1 = b * 20, min(H, b * 20 + 20)
+                link = bool(np.array_equal(gband[y0:y1].view(np.uint32), oband[y0:y1].view(np.uint32)))
+                link_l2 = float(np.sqrt(((gband[y0:y1] - oband[y0:y1]) ** 2).sum(-1)).mean())
+            finally:
+                rctx.close()
+            d = np.sqrt(((film - ref) ** 2).sum(-1))
+            band = d[b * 20:b * 20 + 20]
+            parity = {"mean_per_pixel_l2": float(d.mean()), "max_per_pixel_l2": float(d.max()), "pixels": int(d.size), "spp": spp_total,
+                      "tolerance": 1e-4,
+                      "reference": "device reference-tree mode (traversal mode 5: the reference's rand()-driven tree, its box test and order) at the full size, %.1f s" % t_ref_gpu,
+                      "reference_vs_oracle": {"sample": "band %d of %d at %d spp, oracle/pt_oracle.cc on the CPU" % (b, nbands, low), "bit_identical": link, "mean_per_pixel_l2": link_l2},
+                      "fraction_pixels_identical": float((film == ref).all(-1).mean()), "fraction_pixels_gt_1e-3": float((d > 1e-3).mean()),
+                      "band_through_meshes": {"band": b, "mean_per_pixel_l2": float(band.mean()), "fraction_pixels_identical": float((film[b * 20:b * 20 + 20] == ref[b * 20:b * 20 + 20]).all(-1).mean())},
+                      "note": "the default path walks its own SAH tree: ~3e-4 of the samples through the meshes find a different first hit than the reference's rand()-driven tree does (fringe hits, DESIGN.md Numerics)",
+                      "libm_sincosf": int(bi.libm_sincosf)}
+            cpu_spp = 4
+        # CPU baseline: the whole frame at a reduced spp (throughput does not depend on spp), 20-row tasks, stock sampler
         pc = jp.render_params(W, H, cpu_spp, 5, 1234, sampler_mode=jp.JP_SAMPLER_STOCK_MT19937)
-        t1 = time.perf_counter(); Hn.oracle_render(scene, pc, threads); t_port = time.perf_counter() - t1
-        port_v = W * H * cpu_spp / t_port / 1e6
-        cpu = {"value": round(port_v, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+        nsamp = W * H * cpu_spp
+        t1 = time.perf_counter(); Hn.oracle_render(scene, pc, t16); t_port = time.perf_counter() - t1
+        cpu = {"value": round(nsamp / t_port / 1e6, 3), "unit": "Msamples/s", "cores": t16, "kind": "port",
                "sample": "whole %dx%d frame at %d spp = %d samples in %.1f s; oracle/pt_oracle.cc, stock mt19937_64 sampler, 20-row tasks on %d std::threads (of %d visible CPUs)" % (
-                   W, H, cpu_spp, W * H * cpu_spp, t_port, threads, avail)}
+                   W, H, cpu_spp, nsamp, t_port, t16, avail)}
         if Hn.have_ref():
             try:
-                rb = scenes.build_cornell(Hn.RefBackend("bench"), W, H, lambert_only=not args.full_materials)
-                t1 = time.perf_counter(); rb.render(W, H, cpu_spp, 5, 0, 1234, threads); t_ref = time.perf_counter() - t1
-                cpu = {"value": round(W * H * cpu_spp / t_ref / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "reference",
+                rb = build_scene(scenes, Hn.RefBackend("bench"), scene_key, W, H)
+                t1 = time.perf_counter(); rb.render(W, H, cpu_spp, 5, 0, 1234, t16); t_ref = time.perf_counter() - t1
+                cpu = {"value": round(nsamp / t_ref / 1e6, 3), "unit": "Msamples/s", "cores": t16, "kind": "reference",
                        "sample": "whole %dx%d frame at %d spp = %d samples in %.1f s; oracle/_ref (unmodified reference: DoRender per 20-row task on its FParallelSystem, FRandomSampler), %d threads (of %d visible CPUs)" % (
-                           W, H, cpu_spp, W * H * cpu_spp, t_ref, threads, avail),
-                       "port_value": round(port_v, 3)}
+                           W, H, cpu_spp, nsamp, t_ref, t16, avail),
+                       "port_value": round(nsamp / t_port / 1e6, 3)}
+                if tb != t16:
+                    t1 = time.perf_counter(); rb.render(W, H, cpu_spp, 5, 0, 1234, tb); t_refb = time.perf_counter() - t1
+                    cpu["at_min_cores_bands"] = {"value": round(nsamp / t_refb / 1e6, 3), "cores": tb,
+                                                 "note": "threads = min(visible CPUs, %d bands): every 20-row task of the reference on its own thread" % nbands}
             except Exception as e:                         # the prebuilt reference library is optional on the GPU box
                 cpu["reference_error"] = str(e)
+        if tb != t16 and "at_min_cores_bands" not in cpu:
+            t1 = time.perf_counter(); Hn.oracle_render(scene, pc, tb); t_pb = time.perf_counter() - t1
+            cpu["at_min_cores_bands"] = {"value": round(nsamp / t_pb / 1e6, 3), "cores": tb, "kind": "port"}
+        return cpu, parity
 
+    # ---- headline ----------------------------------------------------------------------------------------------------------
+    hk, hw, hh, hspp = CONFIGS[args.config]
+    if args.full_materials:
+        hk = "cornell"
+    if args.scene:
+        hk = args.scene
+    hw = args.width or hw; hh = args.height or hh; hspp = args.spp or hspp
+    sub_ids = [int(x) for x in args.configs.split(",") if x.strip()] if (n == 1 and args.configs) else []
+    sub_ids = [i for i in sub_ids if i in (1, 2, 3)]
+    custom = bool(args.scene or args.width or args.height or args.spp or args.full_materials or args.config != 2)
+    if custom:
+        sub_ids = [] if args.configs == "1,2,3" else sub_ids          # a custom headline runs alone unless sub-records are asked for
+    head_in_sub = (not custom) and 2 in sub_ids
+    head, band_rows, lanes = run_workload(hk, hw, hh, hspp, args.steps, args.warmup, with_cpu=not head_in_sub)
+    subs = {}
+    for i in sub_ids:
+        k, w, h, s = CONFIGS[i]
+        rec, _, _ = run_workload(k, w, h, s, 0, 1, min_seconds=args.min_seconds)
+        if rank == 0:
+            subs["configs[%d]" % i] = rec
     if rank == 0:
+        if head_in_sub:                                       # the headline's CPU / parity legs are those of its long sub-record
+            head["cpu_baseline"] = subs["configs[2]"]["cpu_baseline"]; head["l2_vs_cpu_ref"] = subs["configs[2]"]["l2_vs_cpu_ref"]
         out = {
             "metric": "Msamples/sec (whole node) + per-pixel L2 vs CPU ref, cornell_box 1024spp",
-            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": head["value"], "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": args.scaling if n > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cornell_box %dx%d, %d spp (%d per GPU share), %s, maxDepth 5, counter sampler seed 1234" % (
-                W, H, spp_total, args.spp, "full bsdf.cc + microfacet.cc materials" if args.full_materials else "Lambertian-only BSDF"),
-                "parallelism": ("%d-row band shard x%d + RCCL film reduce" % (band_rows, n) if n > 1 else "single GPU") + lanes_note},
-            "roofline": roof, "cpu_baseline": cpu, "l2_vs_cpu_ref": parity,
+            "config": {"workload": head["workload"],
+                       "parallelism": ("%d-row band shard x%d + RCCL film reduce" % (band_rows, n) if n > 1 else "single GPU") + ", %d stream lanes per GPU" % lanes},
+            "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"], "l2_vs_cpu_ref": head["l2_vs_cpu_ref"],
+            "timed_region_s": head["timed_region_s"],
         }
+        if subs:
+            out["configs"] = subs
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -65,7 +65,7 @@ struct SceneView
 	int n_env;
 	float world_radius;
 	JpCamera cam;
-	const float4* flat; const int* flat_leaf; int n_flat;   // tiny scenes: leaf boxes + (first | count-1 << 24), <= 32 leaves, padded to x4
+	const float4* flat; int n_flat;        // tiny scenes: <= 32 leaf boxes with the bit set of their primitives (<= 64), flat_boxes
 	const uint4* wide; int n_wide;          // large scenes: 8-wide quantised nodes, 5 x 16 bytes each (traverse_wide)
 };
 
@@ -253,48 +253,73 @@ __device__ __forceinline__ int traverse_ref(const float4* __restrict__ nodes, co
 	return hit;
 }
 
-// Tiny scenes (<= 32 BVH leaves, e.g. the 32-triangle Cornell box): the tree is collapsed into ONE wide node whose
-// children are the leaves.  Phase 1 tests every leaf box with wave-UNIFORM control flow and uniform (scalar /
-// broadcast) operands -- no stack, no pointer chasing, all 64 lanes busy -- and records the boxes the ray enters
-// in a per-lane bit mask.  Phase 2 walks the lane's own set bits and runs the exact primitive tests.  For the
-// Cornell box this replaces ~6-8 dependent binary-node steps per ray by 17 independent slab tests.
-// flat[2i] = (box min xyz, -), flat[2i+1] = (box max xyz, -); the list is padded to a multiple of 4 with boxes that can
-// never be hit, so the slab loop runs in fully unrolled groups of four (scalar loads issued together).
-// leaf[i] = first device primitive | (count - 1) << 24, kept in LDS (indexed per lane in phase 2).
+// Tiny scenes (<= 32 BVH leaves holding <= 64 primitives, e.g. the 32-triangle Cornell box): the tree is collapsed into ONE
+// wide node whose children are the leaves.  Phase 1 (flat_boxes) tests every leaf box with wave-UNIFORM control flow and
+// uniform (scalar / broadcast) operands -- no stack, no pointer chasing, all 64 lanes busy -- and records the PRIMITIVES of
+// the boxes the ray enters in a per-lane bit mask (one bit per device primitive).  Phase 2 (flat_prims) walks the lane's own
+// set bits and runs the exact primitive tests.  For the Cornell box this replaces ~6-8 dependent binary-node steps per ray by
+// 17 independent slab tests.  The popcount of the mask is the number of primitive tests the ray will pay: the sorted kernels
+// (k_extend_flat / k_shadow_flat, jp_kernels.hip) bin the rays of a tile by it so that the lanes of a wave finish together.
+// flat[2i] = (box min xyz, primitive bits 0..31), flat[2i+1] = (box max xyz, primitive bits 32..63) -- 8 dwords per leaf, all
+// fetched by scalar loads; the loop runs in unrolled groups of four (scalar loads issued together) plus a tail.
+// The reciprocal direction is the hardware approximation (1 ulp): our own boxes are padded by 1e-6 relative and compared
+// with 2e-6 slack, so the test stays conservative; a zero or denormal component gives +-inf, the axis-parallel case.
 typedef const __attribute__((address_space(4))) float* ConstFPtr;       // constant address space: uniform indices become scalar (s_load) loads
-template <bool kAnyHit, int kS, typename PrimPtr>
-__device__ __forceinline__ int traverse_flat(const float4* flat_g, int n_flat4, const int* leaf, PrimPtr prims, V3 o, V3 d, float tmin, float& tmax)
+typedef unsigned long long u64;
+template <bool k64> struct FlatMask { typedef unsigned int type; };
+template <> struct FlatMask<true> { typedef u64 type; };
+template <bool k64> __device__ __forceinline__ int mask_count(typename FlatMask<k64>::type m) { return k64 ? __popcll((u64)m) : __popc((unsigned int)m); }
+
+template <bool k64>
+__device__ __forceinline__ typename FlatMask<k64>::type flat_boxes(const float4* flat_g, int n_flat, V3 o, V3 d, float tmin, float tmax)
 {
+	typedef typename FlatMask<k64>::type M;
 	ConstFPtr flat = (ConstFPtr)flat_g;
-	const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-	unsigned int mask = 0;
-	for (int i0 = 0; i0 < n_flat4; i0 += 4)
+	const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+	M mask = 0;
+	#define JP_FLAT_BOX(i) \
+	{ \
+		const float x0 = (flat[8 * (i) + 0] - o.x) * ix, x1 = (flat[8 * (i) + 4] - o.x) * ix; \
+		const float y0 = (flat[8 * (i) + 1] - o.y) * iy, y1 = (flat[8 * (i) + 5] - o.y) * iy; \
+		const float z0 = (flat[8 * (i) + 2] - o.z) * iz, z1 = (flat[8 * (i) + 6] - o.z) * iz; \
+		const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin)); \
+		const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax)); \
+		M bits = (M)__float_as_uint(flat[8 * (i) + 3]); \
+		if (k64) bits |= (M)((u64)__float_as_uint(flat[8 * (i) + 7]) << 32); \
+		if (tn <= tf * 1.000002f) mask |= bits; \
+	}
+	int i0 = 0;
+	for (; i0 + 4 <= n_flat; i0 += 4)
 	{
 		#pragma unroll
-		for (int u = 0; u < 4; u++)
-		{
-			const int i = i0 + u;
-			const float x0 = (flat[8 * i + 0] - o.x) * ix, x1 = (flat[8 * i + 4] - o.x) * ix;
-			const float y0 = (flat[8 * i + 1] - o.y) * iy, y1 = (flat[8 * i + 5] - o.y) * iy;
-			const float z0 = (flat[8 * i + 2] - o.z) * iz, z1 = (flat[8 * i + 6] - o.z) * iz;
-			const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-			const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
-			if (tn <= tf * 1.000002f) mask |= 1u << i;
-		}
+		for (int u = 0; u < 4; u++) JP_FLAT_BOX(i0 + u)
 	}
+	for (; i0 < n_flat; i0++) JP_FLAT_BOX(i0)
+	#undef JP_FLAT_BOX
+	return mask;
+}
+
+template <bool kAnyHit, bool k64, int kS, typename PrimPtr>
+__device__ __forceinline__ int flat_prims(typename FlatMask<k64>::type mask, PrimPtr prims, V3 o, V3 d, float tmin, float& tmax)
+{
 	int hit = -1;
 #ifdef JP_DBG_FLAT_P1ONLY
-	mask = mask == 0xffffffffu ? 1u : 0u;                        // timing experiment (tools/gpu_shade_split.py): box phase only
+	mask = mask == (typename FlatMask<k64>::type)0x12345677u ? 1u : 0u;   // timing experiment: box phase (and sort) only
 #endif
 	while (mask)
 	{
-		const int i = __ffs((int)mask) - 1;
+		const int p = (k64 ? __ffsll((unsigned long long)mask) : __ffs((int)mask)) - 1;
 		mask &= mask - 1;
-		const int lf = leaf[i], first = lf & 0xffffff, count = ((unsigned int)lf >> 24) + 1;
-		for (int k = 0; k < count; k++)
-			if (prim_hit<kS>(prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) return hit; }
+		if (prim_hit<kS>(prims, p, o, d, tmin, tmax)) { hit = p; if (kAnyHit) return hit; }
 	}
 	return hit;
+}
+
+template <bool kAnyHit, int kS, typename PrimPtr>
+__device__ __forceinline__ int traverse_flat(const float4* flat_g, int n_flat, int n_prims, PrimPtr prims, V3 o, V3 d, float tmin, float& tmax)
+{
+	if (n_prims > 32) return flat_prims<kAnyHit, true, kS>(flat_boxes<true>(flat_g, n_flat, o, d, tmin, tmax), prims, o, d, tmin, tmax);   // wave-uniform branch
+	return flat_prims<kAnyHit, false, kS>(flat_boxes<false>(flat_g, n_flat, o, d, tmin, tmax), prims, o, d, tmin, tmax);
 }
 
 // Large scenes: 8-wide BVH with quantised child boxes (after Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal
