@@ -131,3 +131,21 @@ def test_recursive_integrator_is_the_same_estimator(H, name):
     hb = H.SCENES[name](H.scenes.HostBackend(name), 48, 48)
     ref, _ = H.oracle_render(hb.flatten(), H.jp.render_params(48, 48, 8, 5, 1234), 4)
     assert np.sqrt(((ref - rec) ** 2).sum(-1)).mean() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["cornell", "cornell_lambert"])
+def test_baseline_config0_cpu_plumbing_at_its_size(H, name):
+    """BASELINE.json configs[0]: cornell_box 256x256, 16 spp on the CPU path through parallel.cc (20-row tasks, stock FRandomSampler
+    per task, 16 threads as main.cc:156).  The oracle's film equals the compiled reference's bit for bit: SHA-256 of the raw fp32
+    film, four film rows and the ray statistics from tests/golden/make_golden_config0.py."""
+    import hashlib
+    g = json.load(open(os.path.join(H.GOLDEN, "config0.json")))[name]
+    Wc, Hc, spp = g["width"], g["height"], g["spp"]
+    H.libc_srand(1)
+    hb = H.SCENES[name](H.scenes.HostBackend(name), Wc, Hc)
+    film, cnt = H.oracle_render(hb.flatten(), H.jp.render_params(Wc, Hc, spp, 5, 1234, 0), 16)
+    for y, row in g["rows"].items():
+        assert np.array_equal(film[int(y)].reshape(-1), np.array(row, np.float32)), "row %s differs" % y
+    assert hashlib.sha256(np.ascontiguousarray(film).tobytes()).hexdigest() == g["sha256"]
+    assert [cnt.closest_rays, cnt.closest_hits, cnt.shadow_rays, cnt.shadow_occluded] == g["counts"]
+    assert 3.3 < cnt.closest_rays / (Wc * Hc * spp) < 3.6                                     # SURVEY.md section 8: 3.45 closest-hit rays per sample

@@ -100,3 +100,10 @@ def main(name="cornell_lambert", n=20000):
 
 if __name__ == "__main__":
     main(*(sys.argv[1:2]))
+
+
+def lane_local_order(prims, K):
+    """utilisation when every lane holds K rays and takes them in descending test count (no cross-lane movement)"""
+    m = (len(prims) // (64 * K)) * 64 * K
+    a = np.sort(prims[:m].reshape(-1, K, 64), axis=1)          # per lane: its K rays sorted
+    return prims[:m].sum() / (a.max(2).sum() * 64.0)
