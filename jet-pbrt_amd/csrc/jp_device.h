@@ -67,6 +67,7 @@ struct SceneView
 	JpCamera cam;
 	const float4* flat; int n_flat;        // tiny scenes: <= 32 leaf boxes with the bit set of their primitives (<= 64), flat_boxes
 	const uint4* wide; int n_wide;          // large scenes: 8-wide quantised nodes, 5 x 16 bytes each (traverse_wide)
+	const float4* cut; int n_cut;           // other than tiny scenes: boxes of the <= 16 largest subtrees below the root in the flat_boxes layout (one bit each): the sort key of k_extend_sort / k_shadow_sort
 };
 
 // ---- shape intersection: exact restatements ---------------------------------------------------------------------

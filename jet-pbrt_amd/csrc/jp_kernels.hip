@@ -59,6 +59,7 @@ struct RenderConst
 	int s0, sbatch;      // first sample index and sample count of this batch
 	int n_planes;        // shadow ray planes (lights that can emit)
 	int tiled;           // pixel enumeration: 16 x 4 tiles (1) or row-major (0)
+	int class_mask;      // material classes present in the scene (bit 0: none / null material, bit 1 + JP_MAT_*), k_shade<kSort>
 	int lane_index, lane_count, lane_rows;   // stream lanes: this launch owns the lane_rows-row groups g of the shard's rows with g % lane_count == lane_index
 };
 
@@ -119,6 +120,59 @@ __device__ __forceinline__ void block_prefix2(bool fa, bool fb, unsigned int* s_
 	for (int w = 0; w < JP_BLOCK / 64; w++) { const unsigned int v = t[w]; if (w < wave) base += v; tot += v; }
 	pa = (base & 0xffffu) + (unsigned int)__popcll(ma & lt); ta = tot & 0xffffu;
 	pb = (base >> 16) + (unsigned int)__popcll(mb & lt); tb = tot >> 16;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wavefront-level sort: block-wide STABLE partition of a tile of kRPT x 256 queue entries by a small class key, with wave
+// ballots + popcount prefixes and one block prefix over LDS counters (no atomics: the order is deterministic).
+//   key[r]   class of the entry at tile position r * 256 + tid (>= kClasses: position beyond the tile, not placed)
+//   s_cnt    kClasses * kRPT * 4 counters: entries of class c in (pass r, wave w), class-major -> after the scan their bases
+//   s_idx    s_idx[sorted position] = tile position
+// Three barriers; every thread of the block must call it.  Classes absent from class_mask (uniform) cost one store.
+// Used by k_shade (material class) and by the sorted traversal kernels (expected traversal work).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int kRPT, int kClasses>
+__device__ __forceinline__ void tile_partition(const unsigned int (&key)[kRPT], unsigned int class_mask, unsigned int* s_cnt, unsigned short* s_idx)
+{
+	constexpr int kSeg = kRPT * (JP_BLOCK / 64), kN = kClasses * kSeg;
+	static_assert(kN <= 128, "tile_partition: one wave scans two counters per lane");
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	unsigned int pre[kRPT];
+	#pragma unroll
+	for (int r = 0; r < kRPT; r++)
+	{
+		pre[r] = 0;
+		#pragma unroll
+		for (int c = 0; c < kClasses; c++)
+		{
+			if (!((class_mask >> c) & 1u)) { if (lane == 0) s_cnt[c * kSeg + r * (JP_BLOCK / 64) + wave] = 0; continue; }
+			const unsigned long long m = __ballot(key[r] == (unsigned int)c);
+			if (key[r] == (unsigned int)c) pre[r] = (unsigned int)__popcll(m & lt);
+			if (lane == 0) s_cnt[c * kSeg + r * (JP_BLOCK / 64) + wave] = (unsigned int)__popcll(m);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < 64)
+	{   // exclusive scan of the kN counters by one wave, two per lane
+		const int a = threadIdx.x, b2 = threadIdx.x + 64;
+		const unsigned int va = a < kN ? s_cnt[a] : 0u, vb = b2 < kN ? s_cnt[b2] : 0u;
+		unsigned int ia = va, ib = vb;
+		#pragma unroll
+		for (int off = 1; off < 64; off <<= 1)
+		{
+			const unsigned int ta = __shfl_up(ia, off), tb = __shfl_up(ib, off);
+			if (a >= off) { ia += ta; ib += tb; }
+		}
+		const unsigned int tot_a = __shfl(ia, 63);
+		if (a < kN) s_cnt[a] = ia - va;
+		if (b2 < kN) s_cnt[b2] = tot_a + ib - vb;
+	}
+	__syncthreads();
+	#pragma unroll
+	for (int r = 0; r < kRPT; r++)
+		if (key[r] < (unsigned int)kClasses) s_idx[s_cnt[key[r] * kSeg + r * (JP_BLOCK / 64) + wave] + pre[r]] = (unsigned short)(r * JP_BLOCK + threadIdx.x);
+	__syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -257,11 +311,23 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend(SceneView sc, Queues q, int
 // light) are LDS reads instead of a chain of global loads.
 // kStage (<= 4 emitting lights): the NEE rays of a path are staged in LDS and a shadow entry is allocated only when at
 // least one ray survived the rejections of integrator.cc:362-367, so k_shadow never meets an empty entry.
-template <bool kTab, bool kPrims, bool kStage>
+// kSort ("material sort"): the paths of a 1024-path tile are partitioned by the material class of the primitive they hit (none /
+// matte / mirror / glass / plastic / metal) before they are shaded, with wave ballots + a block prefix over LDS counters, and
+// the tile is then shaded in that order: a wave holds paths of ONE class except at class boundaries, so the microfacet code of
+// bsdf.cc / microfacet.cc runs with full waves on the paths that need it instead of with 10-15 % of the lanes in every wave
+// (measured on the reference's Cornell scene: k_shade 3124 -> wave64 instructions per 64 paths at lane utilisation 0.42 before).
+// The partition is stable, so the big class still reads its records almost in queue order.  Every path computes exactly what it
+// computed before; only the order inside this block's output regions changes.
+#define JP_SHADE_TILE 1024
+#define JP_SHADE_CLASSES 6
+template <bool kTab, bool kPrims, bool kStage, bool kSort>
 __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, RenderConst rc, int cur, DevCounters* cnt)
 {
 	__shared__ unsigned int s_tmp[JP_BLOCK / 64];
 	__shared__ unsigned int s_tmp2[2 * (JP_BLOCK / 64)];
+	constexpr int kRPT = JP_SHADE_TILE / JP_BLOCK, kSeg = kRPT * (JP_BLOCK / 64);       // (pass, wave) segments of a tile, in queue order
+	__shared__ unsigned short s_idx[kSort ? JP_SHADE_TILE : 1];
+	__shared__ unsigned int s_cnt[kSort ? JP_SHADE_CLASSES * kSeg : 1];
 	unsigned int chunk = 0;
 	float4* s_lights = s_dyn;
 	float4* s_mats = s_lights + 2 * sc.n_lights;
@@ -291,15 +357,39 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 	const int4* meta_t = kPrims ? (const int4*)s_meta : sc.meta;
 	const unsigned int rbase = b * q.R;
 	unsigned int run_q = 0, run_sh = 0;                           // block-uniform fill of this block's output regions
+	const unsigned int tile = kSort ? (unsigned int)JP_SHADE_TILE : n;
+	for (unsigned int t0 = 0; t0 < n; t0 += tile)
+	{
+	const unsigned int count = n - t0 < tile ? n - t0 : tile;
+	if (kSort)
+	{   // ---- stable partition of the tile's paths by material class: s_idx[sorted position] = position in the tile ----
+		unsigned int key[kRPT];
+		#pragma unroll
+		for (int r = 0; r < kRPT; r++)
+		{
+			const unsigned int j = r * JP_BLOCK + threadIdx.x;
+			key[r] = JP_SHADE_CLASSES;                               // beyond the tile: no class
+			if (j < count)
+			{
+				const int pi = __float_as_int(q.hit[rbase + t0 + j].y);
+				int m = -1; if (pi >= 0) m = meta_t[pi].y;
+				key[r] = m >= 0 ? 1u + (unsigned int)mat_type[m] : 0u;
+			}
+		}
+		tile_partition<kRPT, JP_SHADE_CLASSES>(key, (unsigned int)rc.class_mask, s_cnt, s_idx);
+	}
 	// software prefetch of the next chunk's path records
 	float4 ro_n = make_float4(0, 0, 0, 0), rd_n = ro_n, rb_n = ro_n; float2 h_n = make_float2(0, 0);
-	if (threadIdx.x < n) { const unsigned int i0 = rbase + threadIdx.x; ro_n = q.ray_o[cur][i0]; rd_n = q.ray_d[cur][i0]; rb_n = q.beta[cur][i0]; h_n = q.hit[i0]; }
-	for (unsigned int j0 = 0; j0 < n; j0 += JP_BLOCK)
+	if (threadIdx.x < count) { const unsigned int i0 = rbase + t0 + (kSort ? (unsigned int)s_idx[threadIdx.x] : threadIdx.x); ro_n = q.ray_o[cur][i0]; rd_n = q.ray_d[cur][i0]; rb_n = q.beta[cur][i0]; h_n = q.hit[i0]; }
+	for (unsigned int j0 = 0; j0 < count; j0 += JP_BLOCK)
 	{
-		const unsigned int i = rbase + j0 + threadIdx.x;
-		const bool valid = j0 + threadIdx.x < n;
+		const bool valid = j0 + threadIdx.x < count;
 		const float4 ro = ro_n, rd = rd_n, rb = rb_n; const float2 h = h_n;
-		if (j0 + JP_BLOCK + threadIdx.x < n) { ro_n = q.ray_o[cur][i + JP_BLOCK]; rd_n = q.ray_d[cur][i + JP_BLOCK]; rb_n = q.beta[cur][i + JP_BLOCK]; h_n = q.hit[i + JP_BLOCK]; }
+		if (j0 + JP_BLOCK + threadIdx.x < count)
+		{
+			const unsigned int i1 = rbase + t0 + (kSort ? (unsigned int)s_idx[j0 + JP_BLOCK + threadIdx.x] : j0 + JP_BLOCK + threadIdx.x);
+			ro_n = q.ray_o[cur][i1]; rd_n = q.ray_d[cur][i1]; rb_n = q.beta[cur][i1]; h_n = q.hit[i1];
+		}
 		bool shaded = false, wantNee = false, alive = false;
 		V3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(0, 0, 0), p = mk(0, 0, 0), N = mk(0, 0, 1);
 		int slot = 0, bounce = 0; bool spec = false; unsigned int dim = 0; uint32_t key = 0;
@@ -476,6 +566,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 			q.beta[nxt][j] = make_float4(nbeta.x, nbeta.y, nbeta.z, __int_as_float((int)key));
 		}
 	}
+	}
 	if (threadIdx.x == 0)
 	{
 		q.blk_q[nxt][b] = run_q; q.blk_sh[b] = run_sh;
@@ -521,6 +612,169 @@ __global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow(SceneView sc, Queues q, 
 			else { a = a + xyz(c4); any = true; }
 		}
 		if (any) q.lacc[slot] = make_float4(a.x, a.y, a.z, 0.f);
+	}
+	for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); occ += __shfl_down(occ, off); }
+	if ((threadIdx.x & 63) == 0) { if (rays) atomicAdd(&cnt->shadow, (unsigned long long)rays); if (occ) atomicAdd(&cnt->shadow_occ, (unsigned long long)occ); }
+}
+
+#define JP_SORT_TILE 1024
+#define JP_SORT_CLASSES 6
+// expected-work class of a ray: tiny scenes (mode 2) -- the number of primitive tests it will pay (popcount of the box-phase
+// mask, tools/flat_stats.py: mean 3.3, the unluckiest of 64 lanes ~10); other scenes -- the number of "cut" subtrees (the
+// largest subtrees below the root, <= 16 boxes tested wave-uniformly like the flat list) its segment enters
+__device__ __forceinline__ unsigned int work_class_flat(int pc) { return pc <= 1 ? 0u : pc == 2 ? 1u : pc <= 4 ? 2u : pc <= 6 ? 3u : pc <= 8 ? 4u : 5u; }
+__device__ __forceinline__ unsigned int work_class_cut(int pc) { return pc < 5 ? (unsigned int)pc : 5u; }
+
+// k_extend_sort: k_extend with the rays of each 1024-ray tile partitioned by expected work before they are traced, so that the
+// 64 lanes of a wave finish together.  The hit record of every ray goes to the ray's own queue position: k_shade sees what it saw.
+template <int kMode>
+__global__ void __launch_bounds__(JP_BLOCK) k_extend_sort(SceneView sc, Queues q, int cur, int depth, DevCounters* cnt)
+{
+	constexpr int kRPT = JP_SORT_TILE / JP_BLOCK;
+	__shared__ unsigned short s_idx[JP_SORT_TILE];
+	__shared__ unsigned int s_cnt[JP_SORT_CLASSES * kRPT * (JP_BLOCK / 64)];
+	__shared__ u64 s_mask[kMode == 2 ? JP_SORT_TILE : 1];           // mode 2: the box-phase result, so phase 1 runs once
+	SceneAccess<kMode> acc(sc, depth);
+	const unsigned int b = blockIdx.x, n = q.blk_q[cur][b], rbase = b * q.R;
+	if (b == 0 && threadIdx.x == 0) { cnt->closest += cnt->n_queue[cur]; cnt->n_queue[cur ^ 1] = 0; cnt->n_shadow = 0; }
+	const bool w64 = sc.n_prims > 32;
+	unsigned int h = 0;
+	for (unsigned int t0 = 0; t0 < n; t0 += JP_SORT_TILE)
+	{
+		const unsigned int count = n - t0 < (unsigned int)JP_SORT_TILE ? n - t0 : (unsigned int)JP_SORT_TILE;
+		unsigned int key[kRPT];
+		#pragma unroll
+		for (int r = 0; r < kRPT; r++)
+		{
+			const unsigned int j = r * JP_BLOCK + threadIdx.x;
+			key[r] = JP_SORT_CLASSES;
+			if (j < count)
+			{
+				const float4 ro = q.ray_o[cur][rbase + t0 + j], rd = q.ray_d[cur][rbase + t0 + j];
+				if constexpr (kMode == 2)
+				{
+					const u64 m = w64 ? (u64)flat_boxes<true>(sc.flat, sc.n_flat, xyz(ro), xyz(rd), 0.001f, JP_INF) : (u64)flat_boxes<false>(sc.flat, sc.n_flat, xyz(ro), xyz(rd), 0.001f, JP_INF);
+					s_mask[kMode == 2 ? j : 0] = m;
+					key[r] = work_class_flat(__popcll(m));
+				}
+				else key[r] = work_class_cut(__popc(flat_boxes<false>(sc.cut, sc.n_cut, xyz(ro), xyz(rd), 0.001f, JP_INF)));
+			}
+		}
+		tile_partition<kRPT, JP_SORT_CLASSES>(key, 0x3fu, s_cnt, s_idx);
+		// software prefetch: the next pass' ray is requested before this pass' traversal
+		float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 1, 0); unsigned int jn = 0;
+		if (threadIdx.x < count) { jn = s_idx[threadIdx.x]; ro = q.ray_o[cur][rbase + t0 + jn]; rd = q.ray_d[cur][rbase + t0 + jn]; }
+		#pragma unroll 1
+		for (unsigned int p0 = 0; p0 < count; p0 += JP_BLOCK)
+		{
+			const unsigned int pos = p0 + threadIdx.x, j = jn;
+			const float4 co = ro, cd = rd;
+			if (pos + JP_BLOCK < count) { jn = s_idx[pos + JP_BLOCK]; ro = q.ray_o[cur][rbase + t0 + jn]; rd = q.ray_d[cur][rbase + t0 + jn]; }
+			if (pos < count)
+			{
+				float tmax = JP_INF;                                     // FRay defaults geometry.h:399: min_t 0.001, max_t infinity
+				int hit;
+				if constexpr (kMode == 2)
+				{
+					const u64 m = s_mask[kMode == 2 ? j : 0];
+					hit = w64 ? flat_prims<false, true, 5>(m, acc.prims, xyz(co), xyz(cd), 0.001f, tmax) : flat_prims<false, false, 5>((unsigned int)m, acc.prims, xyz(co), xyz(cd), 0.001f, tmax);
+				}
+				else hit = acc.template trace<false>(sc, xyz(co), xyz(cd), 0.001f, tmax);
+				q.hit[rbase + t0 + j] = make_float2(tmax, __int_as_float(hit));
+				h += hit >= 0 ? 1u : 0u;
+			}
+		}
+		__syncthreads();                                             // s_idx / s_mask are rewritten by the next tile
+	}
+	for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off);
+	if ((threadIdx.x & 63) == 0 && h) atomicAdd(&cnt->closest_hit, (unsigned long long)h);
+}
+
+// k_shadow_sort: k_shadow with the ENTRIES of each tile partitioned by the expected work of their rays (summed over the entry's
+// rays).  One lane still owns an entry and adds its visible contributions in light order (integrator.cc:367-370).
+template <int kMode>
+__global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow_sort(SceneView sc, Queues q, RenderConst rc, int depth, DevCounters* cnt)
+{
+	constexpr int kRPT = JP_SORT_TILE / JP_BLOCK;
+	__shared__ unsigned short s_idx[JP_SORT_TILE];
+	__shared__ unsigned int s_cnt[JP_SORT_CLASSES * kRPT * (JP_BLOCK / 64)];
+	__shared__ u64 s_mask[kMode == 2 ? 2 * JP_SORT_TILE : 1];       // mode 2: box-phase masks of the entry's first two rays (further rays redo the phase)
+	SceneAccess<kMode> acc(sc, depth);
+	const unsigned int b = blockIdx.x, E = q.blk_sh[b], rbase = b * q.R;
+	const bool w64 = sc.n_prims > 32;
+	unsigned int rays = 0, occ = 0;
+	for (unsigned int e0 = 0; e0 < E; e0 += JP_SORT_TILE)
+	{
+		const unsigned int count = E - e0 < (unsigned int)JP_SORT_TILE ? E - e0 : (unsigned int)JP_SORT_TILE;
+		unsigned int key[kRPT];
+		#pragma unroll
+		for (int r = 0; r < kRPT; r++)
+		{
+			const unsigned int j = r * JP_BLOCK + threadIdx.x;
+			key[r] = JP_SORT_CLASSES;
+			if (j < count)
+			{
+				const float4 so = q.sh_o[rbase + e0 + j];
+				const int nr = (__float_as_int(so.w) >> 24) & 0xff;
+				int pc = 0;
+				for (int k = 0; k < nr; k++)
+				{
+					const float4 sd = q.sh_d[(size_t)k * q.cap + rbase + e0 + j];
+					if constexpr (kMode == 2)
+					{
+						if (k < 2)
+						{
+							const u64 m = w64 ? (u64)flat_boxes<true>(sc.flat, sc.n_flat, xyz(so), xyz(sd), 0.001f, sd.w) : (u64)flat_boxes<false>(sc.flat, sc.n_flat, xyz(so), xyz(sd), 0.001f, sd.w);
+							s_mask[kMode == 2 ? k * JP_SORT_TILE + j : 0] = m;
+							pc += __popcll(m);
+						}
+					}
+					else pc += __popc(flat_boxes<false>(sc.cut, sc.n_cut, xyz(so), xyz(sd), 0.001f, sd.w));
+				}
+				key[r] = kMode == 2 ? work_class_flat(pc) : work_class_cut(pc);
+			}
+		}
+		tile_partition<kRPT, JP_SORT_CLASSES>(key, 0x3fu, s_cnt, s_idx);
+		float4 so_n = make_float4(0, 0, 0, 0), sd_n = make_float4(0, 0, 1, 0); unsigned int jn = 0;
+		if (threadIdx.x < count) { jn = s_idx[threadIdx.x]; so_n = q.sh_o[rbase + e0 + jn]; sd_n = q.sh_d[rbase + e0 + jn]; }
+		#pragma unroll 1
+		for (unsigned int p0 = 0; p0 < count; p0 += JP_BLOCK)
+		{
+			const unsigned int pos = p0 + threadIdx.x, j = jn, e = rbase + e0 + j;
+			const float4 so = so_n; float4 sd = sd_n;
+			if (pos + JP_BLOCK < count) { jn = s_idx[pos + JP_BLOCK]; so_n = q.sh_o[rbase + e0 + jn]; sd_n = q.sh_d[rbase + e0 + jn]; }
+			if (pos >= count) continue;
+			const int packed = __float_as_int(so.w);
+			const int slot = packed & 0xffffff, nr = (packed >> 24) & 0xff;
+			if (nr == 0) continue;
+			bool any = false;
+			const float4 L = q.lacc[slot];                               // issued up front: its latency hides behind the traversal
+			V3 a = mk(L.x, L.y, L.z);
+			for (int k = 0; k < nr; k++)
+			{
+				const float4 c4 = q.sh_c[(size_t)k * q.cap + e];          // needed only after the traversal
+				float tmax = sd.w;
+				const V3 dir = xyz(sd);
+				if (k + 1 < nr) sd = q.sh_d[(size_t)(k + 1) * q.cap + e];
+				int hit = -1;
+				bool traced = false;
+				if constexpr (kMode == 2)
+				{
+					if (k < 2)
+					{
+						const u64 m = s_mask[k * JP_SORT_TILE + j];
+						hit = w64 ? flat_prims<true, true, 5>(m, acc.prims, xyz(so), dir, 0.001f, tmax) : flat_prims<true, false, 5>((unsigned int)m, acc.prims, xyz(so), dir, 0.001f, tmax);
+						traced = true;
+					}
+				}
+				if (!traced) hit = acc.template trace<true>(sc, xyz(so), dir, 0.001f, tmax);
+				rays++;
+				if (hit >= 0) occ++;
+				else { a = a + xyz(c4); any = true; }
+			}
+			if (any) q.lacc[slot] = make_float4(a.x, a.y, a.z, 0.f);
+		}
+		__syncthreads();                                             // s_idx / s_mask are rewritten by the next tile
 	}
 	for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); occ += __shfl_down(occ, off); }
 	if ((threadIdx.x & 63) == 0) { if (rays) atomicAdd(&cnt->shadow, (unsigned long long)rays); if (occ) atomicAdd(&cnt->shadow_occ, (unsigned long long)occ); }
@@ -971,11 +1225,12 @@ struct JpContext
 	// scene
 	bool have_scene = false;
 	SceneView sv; int stack_depth = 1; bool scene_in_lds = false; size_t lds_bytes = 0, lds_bytes_shadow = 0;
-	void *d_flat = nullptr, *d_wide = nullptr; int trav_mode = 0;
+	void *d_flat = nullptr, *d_wide = nullptr, *d_cut = nullptr; bool ray_sort = false; int trav_mode = 0;
 	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr;
 	int n_planes = 1; bool has_null_material = false; int sincosf_mode = 0;
 	bool build_on_device = false; float build_ms = 0.f; int bvh_height = 0, bvh_nodes = 0;
 	bool tables_in_lds = false, stage_nee = false; size_t shade_lds_bytes = 0;
+	int class_mask = 0x3f; bool shade_sort = false;                                     // k_shade partitions its tiles by material class (scenes with more than one material kind)
 	bool flat_sort = false; int flat_rpt = 4, flat_ept = 2; size_t flat_lds_extend = 0, flat_lds_shadow = 0;   // mode 2: tile-sorted traversal kernels (k_extend_flat / k_shadow_flat)
 	// queues
 	Queues q; unsigned int cap = 0; int planes_alloc = 0; unsigned int blk_alloc = 0; int blocks_per_cu = 16;
@@ -1001,7 +1256,7 @@ struct JpContext
 
 static void free_scene(JpContext* c)
 {
-	void** ps[] = { &c->d_flat, &c->d_wide, &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights };
+	void** ps[] = { &c->d_flat, &c->d_cut, &c->d_wide, &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights };
 	for (void** p : ps) { if (*p) hipFree(*p); *p = nullptr; }
 	c->have_scene = false;
 }
@@ -1448,6 +1703,42 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		}
 	}
 
+	// other scenes: the "cut" -- boxes of the largest subtrees below the root (each >= 64 primitives, at most 16), found by opening
+	// the heaviest subtree again and again.  How many of them a ray's segment enters is the expected-work key of the sorted
+	// traversal kernels (k_extend_sort / k_shadow_sort); the boxes use the flat_boxes layout, one bit each.
+	std::vector<float4> cut;
+	if (!device_build && flat.empty() && s->bvh_left[0] >= 0)
+	{
+		std::vector<int> nprim(s->n_bvh_nodes, 0);
+		{   // primitives per subtree, children before parents (explicit post-order: the tree may be 30+ levels deep, not 1e5)
+			std::vector<std::pair<int, int>> st; st.push_back({ 0, 0 });
+			while (!st.empty())
+			{
+				auto [nd, phase] = st.back(); st.pop_back();
+				if (s->bvh_left[nd] < 0) { nprim[nd] = s->bvh_right[nd]; continue; }
+				if (phase == 0) { st.push_back({ nd, 1 }); st.push_back({ s->bvh_left[nd], 0 }); st.push_back({ s->bvh_right[nd], 0 }); }
+				else nprim[nd] = nprim[s->bvh_left[nd]] + nprim[s->bvh_right[nd]];
+			}
+		}
+		std::vector<int> open; open.push_back(0);
+		for (;;)
+		{
+			int best = -1;
+			for (size_t k = 0; k < open.size(); k++) if (s->bvh_left[open[k]] >= 0 && nprim[open[k]] >= 128 && (best < 0 || nprim[open[k]] > nprim[open[best]])) best = (int)k;
+			if (best < 0 || open.size() >= 16) break;
+			const int nd = open[best]; open.erase(open.begin() + best);
+			open.push_back(s->bvh_left[nd]); open.push_back(s->bvh_right[nd]);
+		}
+		int bit = 0;
+		for (int nd : open)
+		{
+			if (nprim[nd] < 64) continue;
+			float bb[6]; pad_box(nd, bb);
+			const uint32_t lo = 1u << bit++; float flo; std::memcpy(&flo, &lo, 4);
+			cut.push_back(make_float4(bb[0], bb[1], bb[2], flo)); cut.push_back(make_float4(bb[3], bb[4], bb[5], 0.f));
+		}
+	}
+
 	// materials: the 16-float rows as 4 x float4
 	std::vector<float4> mats(4 * std::max(1, s->n_materials)); std::vector<int> mtype(std::max(1, s->n_materials), 0);
 	for (int i = 0; i < s->n_materials; i++) { std::memcpy(&mats[4 * i], s->mat_params + (size_t)i * JP_MAT_PARAM_STRIDE, 16 * sizeof(float)); mtype[i] = s->mat_type[i]; }
@@ -1493,6 +1784,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	HIP_TRY(up(&c->d_lights, lights.data(), lights.size() * sizeof(float4)));
 	if (use_wide && !dev_wide) HIP_TRY(up(&c->d_wide, wide.data(), wide.size() * sizeof(uint32_t)));
 	if (!flat.empty()) HIP_TRY(up(&c->d_flat, flat.data(), flat.size() * sizeof(float4)));
+	if (!cut.empty()) HIP_TRY(up(&c->d_cut, cut.data(), cut.size() * sizeof(float4)));
 
 	SceneView& v = c->sv;
 	v.nodes = (const float4*)c->d_nodes; v.n_nodes = (int)(n4nodes / 4);
@@ -1502,6 +1794,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.env_sum = make_float3(envsum[0], envsum[1], envsum[2]); v.n_env = nenv;
 	v.world_radius = s->world_radius; v.cam = s->camera;
 	v.flat = (const float4*)c->d_flat; v.n_flat = (int)(flat.size() / 2);
+	v.cut = (const float4*)c->d_cut; v.n_cut = (int)(cut.size() / 2);
 	v.wide = (const uint4*)c->d_wide; v.n_wide = dev_wide ? dev_n_wide : (int)(wide.size() / 20);
 	c->stack_depth = std::max(2, height + 2);
 	size_t scene_bytes = (n4nodes + n4prims) / 4 * 5 * sizeof(float4);   // 80-byte LDS record stride
@@ -1526,6 +1819,15 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		if (c->stage_nee) c->shade_lds_bytes += 16 + (size_t)std::max(1, planes) * 2 * JP_BLOCK * sizeof(float4);
 	}
 	c->n_planes = std::max(1, planes);
+	{   // material sort in k_shade: pays when the primitives carry more than one material kind (JETPBRT_SHADE_SORT = 0 / 1 forces it)
+		bool kinds[8] = { false, false, false, false, false, false, false, false }; int nk = 0;
+		for (int i = 0; i < s->n_primitives; i++) { const int m = s->prim_material[i]; const int k = m < 0 ? 7 : s->mat_type[m]; if (!kinds[k]) { kinds[k] = true; nk++; } }
+		c->ray_sort = false;                                        // opt-in: JETPBRT_RAY_SORT=1 (tiny scenes: by primitive-test count; others: by cut boxes entered)
+		if (const char* e = getenv("JETPBRT_RAY_SORT")) c->ray_sort = atoi(e) != 0 && (c->trav_mode == 2 || ((c->trav_mode == 0 || c->trav_mode == 3) && !cut.empty()));
+		c->shade_sort = nk > 1;
+		c->class_mask = 1; for (int k = 0; k < 5; k++) if (kinds[k]) c->class_mask |= 2 << k;
+		if (const char* e = getenv("JETPBRT_SHADE_SORT")) c->shade_sort = atoi(e) != 0;
+	}
 	{   // mode 2: the tile-sorted traversal kernels (k_extend_flat / k_shadow_flat); JETPBRT_FLAT_SORT=0 keeps the unsorted pair
 		c->flat_sort = false;                                       // opt-in while it is being tuned (measured: fewer instructions, no less time yet)
 		if (const char* e = getenv("JETPBRT_FLAT_SORT")) c->flat_sort = atoi(e) != 0 && c->trav_mode == 2 && c->n_planes <= 4;
@@ -1630,7 +1932,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 
 		RenderConst rc; rc.width = rp->width; rc.height = rp->height; rc.spp = rp->spp; rc.max_depth = rp->max_depth; rc.seed = rp->seed;
 		rc.band_rows = band; rc.shard_index = sidx; rc.shard_count = scount; rc.npix = (int)npix; rc.local_rows = local_rows; rc.n_planes = c->n_planes;
-		rc.lane_index = lane_index; rc.lane_count = lane_count; rc.lane_rows = lane_group;
+		rc.lane_index = lane_index; rc.lane_count = lane_count; rc.lane_rows = lane_group; rc.class_mask = c->class_mask;
 		// measured: +6 % on the 280k-triangle scene (cache reuse), -8 % on the LDS-resident Cornell box (coherent waves finish
 		// together or not at all, which unbalances the workgroups) -> tiles only when traversal goes through global memory
 		rc.tiled = (c->trav_mode == 0 && rp->width % 16 == 0 && local_rows % 4 == 0 && !getenv("JETPBRT_NO_TILES")) ? 1 : 0;
@@ -1663,7 +1965,12 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 				}
 				{
 					Stamper t(c, CLS_EXTEND);
-					if (c->flat_sort)
+					if (c->ray_sort)
+					{
+						if (c->trav_mode == 2) hipLaunchKernelGGL(k_extend_sort<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
+						else hipLaunchKernelGGL(k_extend_sort<0>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
+					}
+					else if (c->flat_sort)
 					{
 						const bool w = c->sv.n_prims > 32;
 						#define JP_LAUNCH_EF(R, W) hipLaunchKernelGGL((k_extend_flat<R, W>), dim3(grid), dim3(JP_BLOCK), c->flat_lds_extend, c->stream, c->sv, c->q, cur, c->d_cnt)
@@ -1680,7 +1987,8 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 				{
 					Stamper t(c, CLS_SHADE);
 					const bool st = c->stage_nee;
-					#define JP_LAUNCH_SHADE(A, B, C) hipLaunchKernelGGL((k_shade<A, B, C>), dim3(grid), dim3(JP_BLOCK), c->shade_lds_bytes, c->stream, c->sv, c->q, rc, cur, c->d_cnt)
+					#define JP_LAUNCH_SHADE(A, B, C) do { if (c->shade_sort) hipLaunchKernelGGL((k_shade<A, B, C, true>), dim3(grid), dim3(JP_BLOCK), c->shade_lds_bytes, c->stream, c->sv, c->q, rc, cur, c->d_cnt); \
+					                                   else hipLaunchKernelGGL((k_shade<A, B, C, false>), dim3(grid), dim3(JP_BLOCK), c->shade_lds_bytes, c->stream, c->sv, c->q, rc, cur, c->d_cnt); } while (0)
 					if (c->tables_in_lds && c->scene_in_lds) { if (st) JP_LAUNCH_SHADE(true, true, true); else JP_LAUNCH_SHADE(true, true, false); }
 					else if (c->tables_in_lds) { if (st) JP_LAUNCH_SHADE(true, false, true); else JP_LAUNCH_SHADE(true, false, false); }
 					else JP_LAUNCH_SHADE(false, false, false);
@@ -1689,7 +1997,13 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 				if (it < rp->max_depth || c->has_null_material)                 // at bounce == maxDepth Li() breaks before the NEE (integrator.cc:340-343)
 				{
 					Stamper t(c, CLS_SHADOW);
-					if (c->flat_sort)
+					if (c->ray_sort)
+					{
+						if (c->trav_mode == 2) hipLaunchKernelGGL(k_shadow_sort<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
+						else if (c->trav_mode == 3) hipLaunchKernelGGL(k_shadow_sort<3>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes_shadow, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
+						else hipLaunchKernelGGL(k_shadow_sort<0>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
+					}
+					else if (c->flat_sort)
 					{
 						const bool w = c->sv.n_prims > 32;
 						#define JP_LAUNCH_SF(E, W) hipLaunchKernelGGL((k_shadow_flat<E, W>), dim3(grid), dim3(JP_BLOCK), c->flat_lds_shadow, c->stream, c->sv, c->q, rc, c->d_cnt)
@@ -1748,7 +2062,7 @@ void sync_lane_scene(JpContext* c, JpContext* l)
 {
 	l->have_scene = c->have_scene; l->sv = c->sv; l->stack_depth = c->stack_depth; l->scene_in_lds = c->scene_in_lds;
 	l->lds_bytes = c->lds_bytes; l->lds_bytes_shadow = c->lds_bytes_shadow; l->trav_mode = c->trav_mode; l->n_planes = c->n_planes;
-	l->flat_sort = c->flat_sort; l->flat_rpt = c->flat_rpt; l->flat_ept = c->flat_ept; l->flat_lds_extend = c->flat_lds_extend; l->flat_lds_shadow = c->flat_lds_shadow;
+	l->ray_sort = c->ray_sort; l->shade_sort = c->shade_sort; l->class_mask = c->class_mask; l->flat_sort = c->flat_sort; l->flat_rpt = c->flat_rpt; l->flat_ept = c->flat_ept; l->flat_lds_extend = c->flat_lds_extend; l->flat_lds_shadow = c->flat_lds_shadow;
 	l->has_null_material = c->has_null_material; l->tables_in_lds = c->tables_in_lds; l->stage_nee = c->stage_nee; l->shade_lds_bytes = c->shade_lds_bytes;
 	l->profiling = c->profiling;
 }
