@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define JP_ABI_VERSION 3
+#define JP_ABI_VERSION 4
 
 typedef enum JpStatus {
     JP_OK = 0,
@@ -168,6 +168,15 @@ int  jp_render(JpContext* ctx, const JpRenderParams* params, float* film_rgb_hos
 /* same, film left in device memory (film_rgb_device must hold width*height*3 floats on ctx's device);
  * asynchronous on the context stream unless `sync` != 0.  Used for the multi-GPU reduce. */
 int  jp_render_device(JpContext* ctx, const JpRenderParams* params, void* film_rgb_device, int sync);
+/* the film output step right after the hot path (FFilm::SaveAsImage, film.cc:11-145, main.cc:160): the same render, but the
+ * film leaves the device as 8-bit gamma-encoded RGB -- gamma_encoding of film.h:24, (uint8_t)(pow(Clamp01(x), 1/2.2f) * 255.0),
+ * applied on the GPU after the resolve -- so a BMP / PPM writer downloads width*height*3 BYTES instead of 12 bytes per pixel.
+ * rgb8_host: width*height*3 bytes, row-major, top row first, R G B.  film_rgb_host may be NULL (8-bit image only) or receive
+ * the fp32 film as jp_render does.  The encoding is byte-identical to the host libm's powf: the library tabulates, once per
+ * process, the 255 fp32 thresholds at which the host's gamma_encoding steps (binary search over the float bit patterns of
+ * [0, 1]) and the device counts the thresholds <= x (jp_gamma_thresholds: that table, for tests). */
+int  jp_render_rgb8(JpContext* ctx, const JpRenderParams* params, uint8_t* rgb8_host, float* film_rgb_host);
+int  jp_gamma_thresholds(float* out255);
 int  jp_synchronize(JpContext* ctx);
 
 /* per-kernel-class event timing (adds two events per launch); off by default */

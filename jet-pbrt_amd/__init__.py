@@ -117,6 +117,8 @@ def host_lib():
                                      C.c_void_p, C.POINTER(JpCounters)]
         L.jp_host_render_other.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p]
         L.jp_host_save_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.jp_host_render_ldr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        L.jp_host_gamma_encode.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _host = L
     return _host
 
@@ -139,6 +141,8 @@ def hip_lib():
         L.jp_get_counters.argtypes = [C.c_void_p, C.POINTER(JpCounters)]
         L.jp_get_build_info.argtypes = [C.c_void_p, C.POINTER(JpBuildInfo)]
         L.jp_trace.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 8
+        L.jp_render_rgb8.argtypes = [C.c_void_p, C.POINTER(JpRenderParams), C.c_void_p, C.c_void_p]
+        L.jp_gamma_thresholds.argtypes = [C.c_void_p]
         _hip = L
     return _hip
 
@@ -163,6 +167,14 @@ class Context:
         film = np.zeros((params.height, params.width, 3), np.float32)
         self._check(self.lib.jp_render(self.h, C.byref(params), film.ctypes.data_as(C.c_void_p)))
         return film
+
+    def render_rgb8(self, params, with_film=False):
+        """jp_render_rgb8: the film as 8-bit gamma-encoded RGB (H, W, 3) uint8 [, and the fp32 film]"""
+        import numpy as np
+        rgb8 = np.zeros((params.height, params.width, 3), np.uint8)
+        film = np.zeros((params.height, params.width, 3), np.float32) if with_film else None
+        self._check(self.lib.jp_render_rgb8(self.h, C.byref(params), rgb8.ctypes.data_as(C.c_void_p), film.ctypes.data_as(C.c_void_p) if with_film else None))
+        return (rgb8, film) if with_film else rgb8
 
     def render_device(self, params, device_ptr, sync=False):
         self._check(self.lib.jp_render_device(self.h, C.byref(params), C.c_void_p(device_ptr), 1 if sync else 0))

@@ -212,34 +212,61 @@ __device__ __forceinline__ int traverse(NodePtr nodes, PrimPtr prims, V3 o, V3 d
 // shrinks ray.max_t, which later box tests see.  FBounds3::Intersect geometry.cc:10-30 verbatim: per axis two IEEE divisions,
 // std::min / std::max argument order, `tmax <= tmin` rejects.  With the reference's own tree this returns the reference's hit
 // even where that depends on the topology (hits in the fp32 acceptance fringe outside a triangle's box, subtrees dropped by
-// the strict box test).  nodes: 2 x float4 per node, (min xyz, left bits) (max xyz, right bits); left < 0: leaf with device
-// primitives [-(left) - 1, + right).
+// the strict box test).
+// FBounds3::Intersect geometry.cc:10-30, verbatim: per axis two IEEE divisions, std::min / std::max argument order (NaN-order
+// sensitive), `tmax <= tmin` rejects after every axis.
+__device__ __forceinline__ bool ref_box_exact(float4 n0, float4 n1, V3 o, V3 d, float tmin, float tmax)
+{
+	float bt0 = tmin, bt1 = tmax;
+	{
+		const float lo = (n0.x - o.x) / d.x, hi = (n1.x - o.x) / d.x;
+		bt0 = smax(smin(lo, hi), bt0); bt1 = smin(smax(lo, hi), bt1);
+		if (bt1 <= bt0) return false;
+	}
+	{
+		const float lo = (n0.y - o.y) / d.y, hi = (n1.y - o.y) / d.y;
+		bt0 = smax(smin(lo, hi), bt0); bt1 = smin(smax(lo, hi), bt1);
+		if (bt1 <= bt0) return false;
+	}
+	{
+		const float lo = (n0.z - o.z) / d.z, hi = (n1.z - o.z) / d.z;
+		bt0 = smax(smin(lo, hi), bt0); bt1 = smin(smax(lo, hi), bt1);
+		if (bt1 <= bt0) return false;
+	}
+	return true;
+}
+// The same decision, mostly without the six divisions.  Without NaNs the reference's verdict is  min(far_x, far_y, far_z, tmax)
+// > max(near_x, near_y, near_z, tmin)  (the running interval only shrinks, so the per-axis early rejects are implied by the final
+// one).  With t~ = (b - o) * rcp(d) every slab distance carries a relative error below 4e-7 (fp32 subtraction identical, 1-ulp
+// reciprocal, one rounding), so when the two sides are further apart than 2e-6 of their magnitudes the verdict is the exact
+// verdict; otherwise -- or when any operand is not finite (axis-parallel rays: 0 * inf, inf - inf) -- the exact test decides.
+__device__ __forceinline__ bool ref_box(float4 n0, float4 n1, V3 o, V3 d, V3 rd, float tmin, float tmax)
+{
+	const float x0 = (n0.x - o.x) * rd.x, x1 = (n1.x - o.x) * rd.x;
+	const float y0 = (n0.y - o.y) * rd.y, y1 = (n1.y - o.y) * rd.y;
+	const float z0 = (n0.z - o.z) * rd.z, z1 = (n1.z - o.z) * rd.z;
+	const float t0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+	const float t1 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+	const float s = x0 + x1 + y0 + y1 + z0 + z1;                  // NaN or inf anywhere -> not finite (inf - inf -> NaN)
+	const float margin = 2e-6f * (fabsf(t0) + fabsf(t1));
+	const float gap = t1 - t0;
+	if (fabsf(s) <= 3.0e38f && fabsf(gap) > margin) return gap > 0.f;
+	return ref_box_exact(n0, n1, o, d, tmin, tmax);
+}
+
+// nodes: 2 x float4 per node, (min xyz, left bits) (max xyz, right bits); left < 0: leaf with device primitives [-(left) - 1, + right).
+// (Tried and dropped: both children's boxes in the parent's record, one fetch per interior node and no fetch for rejected children,
+// with the right child's early verdict kept only while no hit was accepted in between -- bit-identical, but the unordered walk
+// accepts hits all the time, so right boxes get tested twice: k_extend 51 -> 66 ms on the 280k-triangle scene.)
 template <bool kAnyHit>
 __device__ __forceinline__ int traverse_ref(const float4* __restrict__ nodes, const float4* __restrict__ prims, V3 o, V3 d, float tmin, float& tmax, int* stack)
 {
+	const V3 rd = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
 	int hit = -1, sp = 0, cur = 0;
 	for (;;)
 	{
 		const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
-		float bt0 = tmin, bt1 = tmax;
-		bool ok;
-		{
-			const float lo = (n0.x - o.x) / d.x, hi = (n1.x - o.x) / d.x;
-			bt0 = smax(smin(lo, hi), bt0); bt1 = smin(smax(lo, hi), bt1);
-			ok = !(bt1 <= bt0);
-		}
-		if (ok)
-		{
-			const float lo = (n0.y - o.y) / d.y, hi = (n1.y - o.y) / d.y;
-			bt0 = smax(smin(lo, hi), bt0); bt1 = smin(smax(lo, hi), bt1);
-			ok = !(bt1 <= bt0);
-		}
-		if (ok)
-		{
-			const float lo = (n0.z - o.z) / d.z, hi = (n1.z - o.z) / d.z;
-			bt0 = smax(smin(lo, hi), bt0); bt1 = smin(smax(lo, hi), bt1);
-			ok = !(bt1 <= bt0);
-		}
+		const bool ok = ref_box(n0, n1, o, d, rd, tmin, tmax);
 		const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
 		if (ok && left >= 0) { stack[sp * JP_BLOCK] = right; sp++; cur = left; continue; }
 		if (ok)

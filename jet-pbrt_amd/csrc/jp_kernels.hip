@@ -1183,6 +1183,27 @@ __global__ void __launch_bounds__(JP_BLOCK) k_resolve(Queues q, RenderConst rc, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// k_tonemap8: gamma_encoding (film.h:24) of the resolved film on the device -> 3 bytes per pixel for the BMP / PPM writers of
+// FFilm::SaveAsImage (film.cc:45-145).  thr[k-1] is the smallest fp32 x in [0, 1] whose host-side gamma_encoding(x) is >= k
+// (host_gamma_thresholds); the byte is the number of thresholds <= x, found by an 8-step binary search in LDS -- identical
+// to the host's powf-based value for every fp32 input by construction, without reproducing powf on the device.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(JP_BLOCK) k_tonemap8(const float* __restrict__ film, unsigned char* __restrict__ rgb8, const float* __restrict__ thr, size_t n)
+{
+	__shared__ float s_thr[256];
+	s_thr[threadIdx.x] = threadIdx.x < 255 ? thr[threadIdx.x] : JP_INF;
+	__syncthreads();
+	for (size_t i = (size_t)blockIdx.x * JP_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * JP_BLOCK)
+	{
+		const float x = clampf(film[i], 0.f, 1.f);                  // Clamp01 (the film is clamped already; NaN cannot occur)
+		int lo = 0;                                                  // number of thresholds known to be <= x
+		#pragma unroll
+		for (int step = 128; step > 0; step >>= 1) if (lo + step <= 255 && s_thr[lo + step - 1] <= x) lo += step;
+		rgb8[i] = (unsigned char)lo;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_trace: test hook, arbitrary rays through the same traversal
 // ---------------------------------------------------------------------------------------------------------------------
 template <int kMode>
@@ -1237,6 +1258,7 @@ struct JpContext
 	std::vector<void*> qbufs;
 	float4* d_pix_acc = nullptr; size_t pix_acc_n = 0;
 	float* d_film = nullptr; size_t film_n = 0;
+	float* d_gamma = nullptr; unsigned char* d_rgb8 = nullptr; size_t rgb8_n = 0; unsigned char* h_rgb8 = nullptr; size_t h_rgb8_n = 0;   // jp_render_rgb8
 	float* h_film = nullptr; size_t h_film_n = 0;                // pinned staging buffer of jp_render (a pageable copy of the film costs ~2 ms)
 	DevCounters* d_cnt = nullptr;
 	// timing
@@ -1299,9 +1321,34 @@ static int probe_host_sincosf()
 	return cached;
 }
 
+// gamma_encoding of film.h:24 exactly as the host computes it (std::pow on floats = powf, product in double, truncation)
+static inline unsigned char host_gamma_encoding(float x)
+{
+	const float c = x < 0.f ? 0.f : (x > 1.f ? 1.f : x);
+	return (unsigned char)(std::pow(c, (float)(1 / 2.2)) * 255.0);
+}
+// thr[k-1] = smallest fp32 x in [0, 1] with host_gamma_encoding(x) >= k, k = 1..255: the floats of [0, 1] are ordered like
+// their bit patterns and the encoding is non-decreasing, so each threshold is a binary search over 0 .. 0x3f800000
+static const float* host_gamma_thresholds()
+{
+	static float thr[255]; static bool done = false;
+	if (!done)
+	{
+		for (int k = 1; k <= 255; k++)
+		{
+			uint32_t lo = 0, hi = 0x3f800000u;                       // enc(lo) < k (enc(0) = 0) ... enc(hi) >= k (enc(1) = 255)
+			while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; float f; std::memcpy(&f, &mid, 4); if (host_gamma_encoding(f) >= k) hi = mid; else lo = mid; }
+			std::memcpy(&thr[k - 1], &hi, 4);
+		}
+		done = true;
+	}
+	return thr;
+}
+
 extern "C" {
 
 const char* jp_last_error(void) { return g_err.c_str(); }
+int jp_gamma_thresholds(float* out255) { if (!out255) return fail(JP_ERR_INVALID_ARGUMENT, "jp_gamma_thresholds: null argument"); std::memcpy(out255, host_gamma_thresholds(), 255 * sizeof(float)); return JP_OK; }
 int jp_abi_version(void) { return JP_ABI_VERSION; }
 int jp_probe_libm_sincosf(void) { return probe_host_sincosf(); }
 
@@ -1342,6 +1389,9 @@ int jp_destroy_context(JpContext* c)
 	if (c->d_pix_acc) hipFree(c->d_pix_acc);
 	if (c->d_film) hipFree(c->d_film);
 	if (c->h_film) hipHostFree(c->h_film);
+	if (c->d_gamma) hipFree(c->d_gamma);
+	if (c->d_rgb8) hipFree(c->d_rgb8);
+	if (c->h_rgb8) hipHostFree(c->h_rgb8);
 	if (c->d_cnt) hipFree(c->d_cnt);
 	for (hipEvent_t e : c->evpool) hipEventDestroy(e);
 	if (c->ev0) hipEventDestroy(c->ev0);
@@ -2177,6 +2227,26 @@ int jp_render(JpContext* c, const JpRenderParams* rp, float* film_host)
 	HIP_TRY(hipMemcpyAsync(stage, c->d_film, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	if (stage != film_host) std::memcpy(film_host, stage, n * sizeof(float));
+	return JP_OK;
+}
+
+int jp_render_rgb8(JpContext* c, const JpRenderParams* rp, uint8_t* rgb8_host, float* film_host)
+{
+	if (!c || !rp || !rgb8_host) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render_rgb8: null argument");
+	if (rp->width <= 0 || rp->height <= 0) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render_rgb8: bad width/height");
+	HIP_TRY(hipSetDevice(c->device));
+	const size_t n = (size_t)rp->width * rp->height * 3;
+	if (c->film_n < n) { if (c->d_film) hipFree(c->d_film); c->d_film = nullptr; HIP_TRY(hipMalloc((void**)&c->d_film, n * sizeof(float))); c->film_n = n; }
+	if (c->rgb8_n < n) { if (c->d_rgb8) hipFree(c->d_rgb8); c->d_rgb8 = nullptr; c->rgb8_n = 0; HIP_TRY(hipMalloc((void**)&c->d_rgb8, n)); c->rgb8_n = n; }
+	if (c->h_rgb8_n < n) { if (c->h_rgb8) hipHostFree(c->h_rgb8); c->h_rgb8 = nullptr; c->h_rgb8_n = 0; if (hipHostMalloc((void**)&c->h_rgb8, n, hipHostMallocDefault) == hipSuccess) c->h_rgb8_n = n; else c->h_rgb8 = nullptr; }
+	if (!c->d_gamma) { HIP_TRY(hipMalloc((void**)&c->d_gamma, 255 * sizeof(float))); HIP_TRY(hipMemcpy(c->d_gamma, host_gamma_thresholds(), 255 * sizeof(float), hipMemcpyHostToDevice)); }
+	int st = render_impl(c, rp, c->d_film, false); if (st != JP_OK) return st;
+	hipLaunchKernelGGL(k_tonemap8, dim3((unsigned int)std::min<size_t>((size_t)c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK)), dim3(JP_BLOCK), 0, c->stream, (const float*)c->d_film, c->d_rgb8, (const float*)c->d_gamma, n);
+	unsigned char* stage = c->h_rgb8 ? c->h_rgb8 : rgb8_host;
+	HIP_TRY(hipMemcpyAsync(stage, c->d_rgb8, n, hipMemcpyDeviceToHost, c->stream));
+	if (film_host) HIP_TRY(hipMemcpyAsync(film_host, c->d_film, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (stage != rgb8_host) std::memcpy(rgb8_host, stage, n);
 	return JP_OK;
 }
 

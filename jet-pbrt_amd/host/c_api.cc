@@ -116,6 +116,28 @@ int jp_host_render_other(void* h, int kind, int W, int H, int spp, int maxdepth,
 	return JP_OK;
 }
 
+// The film output path with the tone map on the device: FFilm::RequestDeviceLDR(ldr_only) -> Render -> the 8-bit pixels (and,
+// unless ldr_only, the fp32 film) -> optionally FFilm::SaveAsImage(filename, type).  rgb8_out: W*H*3 bytes; film_out may be null.
+int jp_host_render_ldr(void* h, int W, int H, int spp, int maxdepth, unsigned seed, int device, int ldr_only, unsigned char* rgb8_out, float* film_out, const char* filename, int type)
+{
+	HostScene* hs = (HostScene*)h;
+	if (!hs->integ || hs->integDepth != maxdepth) { hs->integ.reset(new FGpuPathIntegrator(maxdepth, device)); hs->integDepth = maxdepth; }
+	hs->integ->SetShard(0, 1);
+	FFilm film(W, H);
+	film.RequestDeviceLDR(ldr_only != 0);
+	FCounterSampler sampler(spp, seed);
+	hs->integ->Render(hs->scene.get(), &sampler, &film, 16);
+	if (hs->integ->LastStatus() != JP_OK) return hs->integ->LastStatus();
+	if (!film.HasLDR()) return JP_ERR_DEVICE;
+	if (rgb8_out) std::memcpy(rgb8_out, film.ldr8.data(), film.ldr8.size());
+	if (film_out) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const FColor& c = film(x, y); float* o = film_out + 3 * ((size_t)y * W + x); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
+	if (filename && filename[0]) return film.SaveAsImage(filename, type == 0 ? EImageType::PPM : (type == 2 ? EImageType::HDR : EImageType::BMP)) ? JP_OK : JP_ERR_INVALID_ARGUMENT;
+	return JP_OK;
+}
+
+// gamma_encoding (film.h:24) on the host for n values (tests: the device's bytes must equal these)
+void jp_host_gamma_encode(const float* x, int n, unsigned char* out) { for (int i = 0; i < n; i++) out[i] = gamma_encoding(x[i]); }
+
 // FFilm::SaveAsImage on an rgb buffer (type 0 PPM, 1 BMP, 2 HDR): returns 1 on success
 int jp_host_save_image(const float* rgb, int W, int H, const char* filename, int type)
 {

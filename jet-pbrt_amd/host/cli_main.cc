@@ -104,6 +104,7 @@ int main(int argc, char* argv[])
 	else if (integratorName == "debug") integrator.reset(new FDebugIntegrator());
 	else if (integratorName == "recursive") integrator.reset(new FPathIntegratorRecursive(5));
 	else integrator.reset(new FPathIntegratorIteration(5));
+	if (format != "hdr") film.RequestDeviceLDR(true);             // BMP / PPM: gamma_encoding runs on the GPU, 3 bytes per pixel come back
 	integrator->Render(scene.get(), sampler.get(), &film, 16);    // main.cc:156
 	if (integrator->LastStatus() != JP_OK) return 3;              // no GPU / no library: fail loudly, nothing is written
 	char fullname[512];

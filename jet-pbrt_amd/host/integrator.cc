@@ -21,6 +21,7 @@ struct HipApi
 	int (*destroy_context)(JpContext*) = nullptr;
 	int (*upload_scene)(JpContext*, const JpScene*) = nullptr;
 	int (*render)(JpContext*, const JpRenderParams*, float*) = nullptr;
+	int (*render_rgb8)(JpContext*, const JpRenderParams*, uint8_t*, float*) = nullptr;
 	int (*get_counters)(JpContext*, JpCounters*) = nullptr;
 	std::string error;
 };
@@ -43,7 +44,8 @@ HipApi& Api()
 		api.upload_scene = (int (*)(JpContext*, const JpScene*))dlsym(api.lib, "jp_upload_scene");
 		api.render = (int (*)(JpContext*, const JpRenderParams*, float*))dlsym(api.lib, "jp_render");
 		api.get_counters = (int (*)(JpContext*, JpCounters*))dlsym(api.lib, "jp_get_counters");
-		if (!api.last_error || !api.create_context || !api.destroy_context || !api.upload_scene || !api.render || !api.get_counters)
+		api.render_rgb8 = (int (*)(JpContext*, const JpRenderParams*, uint8_t*, float*))dlsym(api.lib, "jp_render_rgb8");
+		if (!api.last_error || !api.create_context || !api.destroy_context || !api.upload_scene || !api.render || !api.get_counters || !api.render_rgb8)
 		{ api.error = "libjetpbrt_amd.so lacks a required jp_* symbol"; dlclose(api.lib); api.lib = nullptr; }
 	});
 	return api;
@@ -88,14 +90,22 @@ void FGpuPathIntegrator::Render(const FScene* scene, FSampler* sampler, FFilm* f
 	rp.spp = sampler->GetSamplesPerPixel(); rp.max_depth = maxDepth;
 	rp.sampler_mode = JP_SAMPLER_COUNTER; rp.seed = sampler->Seed();
 	rp.band_rows = bandRows; rp.shard_index = shardIndex; rp.shard_count = shardCount; rp.integrator = kind;
-	std::vector<float> rgb((size_t)rp.width * rp.height * 3);
-	lastStatus = api.render(ctx, &rp, rgb.data());
-	if (lastStatus != JP_OK) { fprintf(stderr, "FGpuPathIntegrator::Render: %s\n", api.last_error()); return; }
-	for (int y = 0; y < rp.height; y++) for (int x = 0; x < rp.width; x++)
-	{
-		const float* p = &rgb[3 * ((size_t)y * rp.width + x)];
-		film->AddColor(x, y, FColor(p[0], p[1], p[2]));                   // integrator.cc:108 / film.h:64-68
+	const bool floatFilm = !(film->wantLDR && film->ldrOnly);
+	std::vector<float> rgb(floatFilm ? (size_t)rp.width * rp.height * 3 : 0);
+	if (film->wantLDR)
+	{   // FFilm::RequestDeviceLDR: gamma_encoding (film.h:24) runs on the GPU, the film comes back as 3 bytes per pixel
+		film->ldr8.assign((size_t)rp.width * rp.height * 3, 0);
+		lastStatus = api.render_rgb8(ctx, &rp, film->ldr8.data(), floatFilm ? rgb.data() : nullptr);
+		if (lastStatus != JP_OK) film->ldr8.clear();
 	}
+	else lastStatus = api.render(ctx, &rp, rgb.data());
+	if (lastStatus != JP_OK) { fprintf(stderr, "FGpuPathIntegrator::Render: %s\n", api.last_error()); return; }
+	if (floatFilm)
+		for (int y = 0; y < rp.height; y++) for (int x = 0; x < rp.width; x++)
+		{
+			const float* p = &rgb[3 * ((size_t)y * rp.width + x)];
+			film->AddColor(x, y, FColor(p[0], p[1], p[2]));               // integrator.cc:108 / film.h:64-68
+		}
 	api.get_counters(ctx, &counters);
 	fprintf(stderr, "finish rendering ...\n");
 	fprintf(stderr, "FIntegrator::Render used %f seconds.\n", (float)(counters.render_ms / 1000.0));   // integrator.cc:77-79

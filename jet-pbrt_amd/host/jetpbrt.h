@@ -227,7 +227,13 @@ public:
 	void Clear() { for (auto& p : pixels) p = FColor(); }
 	// the output step right after the hot path (main.cc:160): <filename>.ppm/.bmp/.hdr, gamma 1/2.2 for the 8-bit formats
 	bool SaveAsImage(const std::string& filename, EImageType imgType) const;
+	// Tone mapping on the GPU: ask the integrator for the film as 8-bit gamma-encoded RGB (gamma_encoding of film.h:24 applied on
+	// the device after the resolve, byte-identical to the host's) next to -- or, with ldrOnly, INSTEAD of -- the fp32 pixels: a
+	// BMP / PPM then costs a 3-bytes-per-pixel download instead of 12.  SaveAsImage writes ldr8 when it is present.
+	void RequestDeviceLDR(bool only = true) { wantLDR = true; ldrOnly = only; }
+	bool HasLDR() const { return ldr8.size() == (size_t)width * height * 3; }
 	int width, height; std::vector<FColor> pixels;
+	bool wantLDR = false, ldrOnly = false; std::vector<uint8_t> ldr8;   // R G B per pixel, top row first
 };
 
 // ---- scene ----------------------------------------------------------------------------------------------------

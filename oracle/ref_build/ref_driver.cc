@@ -363,6 +363,16 @@ void ref_bsdf(void* h, int count, int mat, const float* n, const float* wo, cons
 	}
 }
 
+// FFilm::SaveAsImage (film.cc:11-188) of the unmodified reference on a given fp32 film: type 0 PPM, 1 BMP, 2 HDR; writes <filename>.<ext>
+int ref_film_save(const float* rgb, int W, int H, const char* filename, int type)
+{
+	FFilm film(W, H);
+	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const float* p = rgb + 3 * ((size_t)y * W + x); film(x, y) = FColor(p[0], p[1], p[2]); }
+	return film.SaveAsImage(filename, type == 0 ? EImageType::PPM : (type == 2 ? EImageType::HDR : EImageType::BMP)) ? 1 : 0;
+}
+// gamma_encoding (film.h:24) of the reference for n values
+void ref_gamma_encode(const float* x, int n, unsigned char* out) { for (int i = 0; i < n; i++) out[i] = gamma_encoding(x[i]); }
+
 // FLight::Sample_Li of light `li` (Lights() order) from a surface point p with normal n
 void ref_light_sample(void* h, int count, int li, const float* p, const float* n, const float* u2,
                       float* pos, float* wi, float* pdf, float* Li)

@@ -86,6 +86,8 @@ def ref_lib():
         L.ref_li_scripted.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]
         L.ref_stock_stream.argtypes = [C.c_int, _vp]
         L.ref_stock_float2.argtypes = [_vp]
+        L.ref_film_save.argtypes = [_vp, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.ref_gamma_encode.argtypes = [_vp, C.c_int, _vp]
         _ref = L
     return _ref
 

@@ -861,3 +861,28 @@ def test_bench_two_rank_rehearsal_on_one_gpu(H, gpu_ctx, tmp_path):
     assert par is not None and par["mean_per_pixel_l2"] < TOL_L2
     if par["libm_sincosf"] != 0:
         assert par["bit_identical"]
+
+
+def test_device_tone_map_bytes_equal_the_host_gamma_encoding(H, gpu_ctx, tmp_path):
+    """jp_render_rgb8 -- gamma_encoding (film.h:24) applied on the GPU after the resolve, W*H*3 bytes downloaded
+    -- gives exactly the bytes the host computes from the fp32 film (which equals the reference's gamma_encoding: CPU golden test),
+    through the C ABI and through FFilm::RequestDeviceLDR -> SaveAsImage (BMP body = those bytes, bottom-up BGR)."""
+    W, Hh, spp = 120, 90, 16                                     # 360 bytes per row: no BMP padding
+    hb, sp = _scene(H, "misc", W, Hh)
+    gpu_ctx.upload(sp)
+    p = H.jp.render_params(W, Hh, spp)
+    rgb8, film = gpu_ctx.render_rgb8(p, with_film=True)
+    assert np.array_equal(film.view(np.uint32), gpu_ctx.render(p).view(np.uint32))
+    want = np.zeros(film.size, np.uint8)
+    H.jp.host_lib().jp_host_gamma_encode(np.ascontiguousarray(film).ctypes.data, film.size, want.ctypes.data)
+    assert np.array_equal(rgb8.reshape(-1), want) and len(np.unique(rgb8)) > 100
+    only = gpu_ctx.render_rgb8(p)
+    assert np.array_equal(only, rgb8)
+    # host API: LDR-only film -> BMP
+    out8 = np.zeros((Hh, W, 3), np.uint8)
+    base = str(tmp_path / "ldr")
+    st = H.jp.host_lib().jp_host_render_ldr(hb.h, W, Hh, spp, 5, 1234, 0, 1, out8.ctypes.data, None, base.encode(), 1)
+    assert st == 0 and np.array_equal(out8, rgb8)
+    raw = open(base + ".bmp", "rb").read()
+    body = np.frombuffer(raw[54:], np.uint8).reshape(Hh, W, 3)[::-1, :, ::-1]
+    assert len(raw) == 54 + W * Hh * 3 and np.array_equal(body, rgb8)

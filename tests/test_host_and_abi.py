@@ -21,7 +21,7 @@ def test_abi_exports_every_declared_symbol(H):
     lib = C.CDLL(H.jp.HIP_LIB_PATH)
     for n in names:
         assert hasattr(lib, n), "libjetpbrt_amd.so does not export %s" % n
-    assert lib.jp_abi_version() == 3
+    assert lib.jp_abi_version() == 4
 
 
 def test_abi_struct_layout_matches_header(H):
@@ -235,3 +235,33 @@ def test_libm_sincosf_transcription_matches_this_host(H):
     (glibc 2.35) it must match, otherwise the bit-identical film tests would silently fall back to a tolerance"""
     lib = C.CDLL(H.jp.HIP_LIB_PATH)
     assert lib.jp_probe_libm_sincosf() in (1, 2)
+
+
+def test_film_writers_equal_the_reference_writers_byte_for_byte(H, tmp_path):
+    """golden BMP / HDR bytes written by the reference's own film.cc (tests/golden/make_golden_film_io.py; a
+    width whose rows need no padding, pixels >= 1e-32 -- where the reference's writers are correct) against this host's writers,
+    and gamma_encoding (film.h:24) around every step of the 8-bit curve against the host mirror AND against the threshold table the
+    device tone map uses (jp_gamma_thresholds: byte = number of thresholds <= x)."""
+    g = np.load(os.path.join(H.GOLDEN, "film_io.npz"))
+    film = np.ascontiguousarray(g["film"]); Hh, W = film.shape[:2]
+    L = H.jp.host_lib()
+    base = str(tmp_path / "img")
+    for t, ext in ((1, "bmp"), (2, "hdr")):
+        assert L.jp_host_save_image(film.ctypes.data, W, Hh, base.encode(), t) == 1
+        mine = np.frombuffer(open(base + "." + ext, "rb").read(), np.uint8)
+        assert mine.size == g["file_" + ext].size and np.array_equal(mine, g["file_" + ext]), ext
+    x = np.ascontiguousarray(g["gamma_x"]); want = g["gamma_y"]
+    got = np.zeros(x.size, np.uint8)
+    L.jp_host_gamma_encode(x.ctypes.data, x.size, got.ctypes.data)
+    assert np.array_equal(got, want)
+    thr = np.zeros(255, np.float32)
+    assert C.CDLL(H.jp.HIP_LIB_PATH).jp_gamma_thresholds(thr.ctypes.data_as(C.c_void_p)) == 0
+    assert (np.diff(thr) >= 0).all() and thr[0] > 0 and thr[-1] <= 1.0
+    table = np.searchsorted(thr, np.clip(x, 0, 1), side="right").astype(np.uint8)        # what k_tonemap8 computes
+    assert np.array_equal(table, want)
+    if H.have_ref():                                              # live, where the reference library exists: a larger random set
+        rng = np.random.default_rng(5)
+        xr = np.concatenate([rng.random(200000), rng.random(50000) ** 8]).astype(np.float32)
+        yr = np.zeros(xr.size, np.uint8)
+        H.ref_lib().ref_gamma_encode(H.ptr(xr), xr.size, H.ptr(yr))
+        assert np.array_equal(np.searchsorted(thr, xr, side="right").astype(np.uint8), yr)

@@ -29,8 +29,8 @@ def main():
         try:
             ctx = jp.Context(0); ctx.upload(sp)
             p = jp.render_params(W, Hh, spp)
-            ctx.render(jp.render_params(W, Hh, min(spp, 64)))
-            t0 = time.perf_counter(); film = ctx.render(p); dt = time.perf_counter() - t0
+            ctx.render(p)                                       # warm: allocations, lanes, clocks
+            t0 = time.perf_counter(); film = ctx.render(p); film = ctx.render(p); dt = (time.perf_counter() - t0) / 2
             lanes = ctx.build_info().lanes_last_render
             os.environ["JETPBRT_LANES"] = kv.get("JETPBRT_LANES", "1")
             ctx.set_profiling(True); ctx.render(p); c = ctx.counters(); ctx.set_profiling(False)
