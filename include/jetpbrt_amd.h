@@ -41,7 +41,9 @@ enum { JP_MAT_MATTE = 0, JP_MAT_MIRROR = 1, JP_MAT_GLASS = 2, JP_MAT_PLASTIC = 3
 enum { JP_LIGHT_ENVIRONMENT = 0, JP_LIGHT_AREA = 1, JP_LIGHT_POINT = 2, JP_LIGHT_DIRECTION = 3 };
 /* sampler: the stock sequential mt19937_64 stream (sampler.h:16-54) cannot be reproduced by a parallel
  * device; the device path implements the counter-based stream of include/jp_counter_rng.h only. */
-enum { JP_SAMPLER_STOCK_MT19937 = 0, JP_SAMPLER_COUNTER = 1 };
+enum { JP_SAMPLER_STOCK_MT19937 = 0, JP_SAMPLER_COUNTER = 1,
+       JP_SAMPLER_DEBUG = 2 };  /* FDebugSampler sampler.h:109-127: every draw is 0.5, the camera sample is the pixel + (0.5, 0.5) (what the body of its
+                                 * GetCameraSample computes; the reference's function lacks its return statement)                                  */
 /* integrators (integrator.h): PATH = FPathIntegratorIteration (integrator.cc:316-403; FPathIntegratorRecursive is the same
  * estimator); WHITTED = FWhittedIntegrator (integrator.cc:115-220; branches at mirrors, one thread walks a sample's whole
  * tree); DEBUG_NORMAL = FDebugIntegrator (integrator.h:44-58).  The last two are API completeness, not the hot path. */
@@ -183,6 +185,32 @@ int  jp_synchronize(JpContext* ctx);
 int  jp_set_profiling(JpContext* ctx, int enabled);
 int  jp_get_counters(JpContext* ctx, JpCounters* out);
 int  jp_get_build_info(JpContext* ctx, JpBuildInfo* out);
+
+/* A BSDF of bsdf.h / bsdf.cc / microfacet.cc described by value: every class of the reference's reflection API, including the
+ * ones no material instantiates (FPhongSpecularReflection bsdf.h:557-633, BeckmannDistribution microfacet.cc:11-254,
+ * FMicrofacetTransmission bsdf.cc:80-145, FresnelNoOp bsdf.h:664-667). */
+enum { JP_BSDF_LAMBERT = 0, JP_BSDF_MIRROR = 1, JP_BSDF_FRESNEL_SPECULAR = 2, JP_BSDF_MICROFACET_REFLECTION = 3,
+       JP_BSDF_MICROFACET_TRANSMISSION = 4, JP_BSDF_PHONG = 5 };
+enum { JP_DIST_TROWBRIDGE_REITZ = 0, JP_DIST_BECKMANN = 1 };
+enum { JP_FRESNEL_CONDUCTOR = 0, JP_FRESNEL_DIELECTRIC = 1, JP_FRESNEL_NOOP = 2 };
+typedef struct JpBsdfDesc
+{
+    int32_t kind;                /* JP_BSDF_*                                                                                   */
+    float   color[3];            /* albedo / R / Kr / T / Ks                                                                    */
+    float   color2[3];           /* FRESNEL_SPECULAR: Kt                                                                        */
+    float   eta_a, eta_b;        /* FRESNEL_SPECULAR: etaI, etaT; MICROFACET_TRANSMISSION: etaA, etaB                           */
+    int32_t distribution;        /* JP_DIST_*       (microfacet kinds)                                                          */
+    float   alpha_x, alpha_y;    /* as handed to the distribution's constructor (clamped to >= 0.001 there)                     */
+    int32_t sample_visible;      /* sampleVisibleArea (microfacet.h:33-39)                                                      */
+    int32_t fresnel;             /* JP_FRESNEL_*    (MICROFACET_REFLECTION)                                                     */
+    float   fr_eta_i[3], fr_eta_t[3], fr_k[3];   /* conductor: etaI, etaT, k; dielectric: fr_eta_i[0], fr_eta_t[0]              */
+    float   exponent;            /* PHONG                                                                                        */
+} JpBsdfDesc;
+/* test hook / utility: FBSDF::Evalf, ::Pdf and ::Sample (bsdf.h:284-302) of `desc` for n shading events on the device.  Host arrays:
+ * normal / wo / wi 3n floats (world space; the frame is FFrame(normal), geometry.h:345-349), u 2n floats ->
+ * f_eval 3n, pdf_eval n (for wo, wi); s_f 3n, s_wi 3n, s_pdf n, s_flags n (eBSDFType bits) for Sample(wo, u). */
+int  jp_bsdf(JpContext* ctx, const JpBsdfDesc* desc, int32_t n, const float* normal, const float* wo, const float* wi, const float* u,
+             float* f_eval, float* pdf_eval, float* s_f, float* s_wi, float* s_pdf, int32_t* s_flags);
 
 /* test hook: closest-hit query for n rays (FScene::Intersect, scene.cc:25-33).  Host arrays:
  * origin/dir 3n floats, tmin/tmax n floats -> hit (0/1), t (ray.max_t after the call), prim (-1 if none),

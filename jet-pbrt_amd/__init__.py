@@ -17,7 +17,7 @@ HOST_LIB_PATH = os.path.join(PKG_DIR, "host", "libjetpbrt_host.so")
 CLI_PATH = os.path.join(PKG_DIR, "host", "jetpbrt")
 
 JP_MAT_PARAM_STRIDE = 16
-JP_SAMPLER_STOCK_MT19937, JP_SAMPLER_COUNTER = 0, 1
+JP_SAMPLER_STOCK_MT19937, JP_SAMPLER_COUNTER, JP_SAMPLER_DEBUG = 0, 1, 2
 JP_OK = 0
 
 _fp = C.POINTER(C.c_float)
@@ -66,6 +66,26 @@ class JpBuildInfo(C.Structure):
 
 
 JP_INTEGRATOR_PATH, JP_INTEGRATOR_WHITTED, JP_INTEGRATOR_DEBUG_NORMAL = 0, 1, 2
+
+
+class JpBsdfDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("color", C.c_float * 3), ("color2", C.c_float * 3), ("eta_a", C.c_float), ("eta_b", C.c_float),
+                ("distribution", C.c_int32), ("alpha_x", C.c_float), ("alpha_y", C.c_float), ("sample_visible", C.c_int32), ("fresnel", C.c_int32),
+                ("fr_eta_i", C.c_float * 3), ("fr_eta_t", C.c_float * 3), ("fr_k", C.c_float * 3), ("exponent", C.c_float)]
+
+
+JP_BSDF_LAMBERT, JP_BSDF_MIRROR, JP_BSDF_FRESNEL_SPECULAR, JP_BSDF_MICROFACET_REFLECTION, JP_BSDF_MICROFACET_TRANSMISSION, JP_BSDF_PHONG = range(6)
+JP_DIST_TROWBRIDGE_REITZ, JP_DIST_BECKMANN = 0, 1
+JP_FRESNEL_CONDUCTOR, JP_FRESNEL_DIELECTRIC, JP_FRESNEL_NOOP = 0, 1, 2
+
+
+def bsdf_desc(kind, color=(1, 1, 1), color2=(1, 1, 1), eta_a=1.0, eta_b=1.5, distribution=0, alpha=(0.2, 0.2), sample_visible=True, fresnel=0,
+              fr_eta_i=(1, 1, 1), fr_eta_t=(1.5, 1.5, 1.5), fr_k=(0, 0, 0), exponent=10.0):
+    d = JpBsdfDesc()
+    d.kind = kind; d.color[:] = color; d.color2[:] = color2; d.eta_a = eta_a; d.eta_b = eta_b; d.distribution = distribution
+    d.alpha_x, d.alpha_y = alpha; d.sample_visible = 1 if sample_visible else 0; d.fresnel = fresnel
+    d.fr_eta_i[:] = fr_eta_i; d.fr_eta_t[:] = fr_eta_t; d.fr_k[:] = fr_k; d.exponent = exponent
+    return d
 
 
 def render_params(width, height, spp, max_depth=5, seed=1234, sampler_mode=JP_SAMPLER_COUNTER,
@@ -119,6 +139,8 @@ def host_lib():
         L.jp_host_save_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
         L.jp_host_render_ldr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
         L.jp_host_gamma_encode.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.jp_host_bsdf_class.argtypes = [C.c_int, _fp, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, _fp, _fp, _fp, _fp, _fp]
+        L.jp_host_render_sampler.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _host = L
     return _host
 
@@ -143,6 +165,7 @@ def hip_lib():
         L.jp_trace.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 8
         L.jp_render_rgb8.argtypes = [C.c_void_p, C.POINTER(JpRenderParams), C.c_void_p, C.c_void_p]
         L.jp_gamma_thresholds.argtypes = [C.c_void_p]
+        L.jp_bsdf.argtypes = [C.c_void_p, C.POINTER(JpBsdfDesc), C.c_int32] + [C.c_void_p] * 10
         _hip = L
     return _hip
 
@@ -204,6 +227,17 @@ class Context:
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         self._check(self.lib.jp_trace(self.h, n, p(o), p(d), p(t0), p(t1), p(hit), p(t), p(prim), p(nrm)))
         return hit, t, prim, nrm
+
+    def bsdf(self, desc, normal, wo, wi, u):
+        """jp_bsdf: FBSDF::Evalf / Pdf / Sample of a by-value BSDF on the device -> dict of arrays"""
+        import numpy as np
+        n = normal.shape[0]
+        a = [np.ascontiguousarray(x, np.float32) for x in (normal, wo, wi, u)]
+        out = dict(f=np.zeros((n, 3), np.float32), pdf=np.zeros(n, np.float32), sf=np.zeros((n, 3), np.float32), swi=np.zeros((n, 3), np.float32),
+                   spdf=np.zeros(n, np.float32), sflags=np.zeros(n, np.int32))
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        self._check(self.lib.jp_bsdf(self.h, C.byref(desc), n, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(out["f"]), p(out["pdf"]), p(out["sf"]), p(out["swi"]), p(out["spdf"]), p(out["sflags"])))
+        return out
 
     def close(self):
         if self.h:

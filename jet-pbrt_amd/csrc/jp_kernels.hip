@@ -15,6 +15,7 @@
 // and appends to region b of the output queues with a running offset, so compaction needs no global atomic and the
 // layout is deterministic.  Launches are asynchronous on one stream, no host round trip inside a batch.
 #include "jp_shading.h"
+#include "jp_xbsdf.h"
 
 #include <cstdio>
 #include <cstring>
@@ -59,9 +60,13 @@ struct RenderConst
 	int s0, sbatch;      // first sample index and sample count of this batch
 	int n_planes;        // shadow ray planes (lights that can emit)
 	int tiled;           // pixel enumeration: 16 x 4 tiles (1) or row-major (0)
+	int sampler_debug;   // JP_SAMPLER_DEBUG: every draw is 0.5
 	int class_mask;      // material classes present in the scene (bit 0: none / null material, bit 1 + JP_MAT_*), k_shade<kSort>
 	int lane_index, lane_count, lane_rows;   // stream lanes: this launch owns the lane_rows-row groups g of the shard's rows with g % lane_count == lane_index
 };
+
+// one draw: the counter stream, or FDebugSampler's constant (sampler.h:109-127: GetFloat 0.5, GetFloat2 (0.5, 0.5), camera sample pixel + 0.5)
+__device__ __forceinline__ float rngf(const RenderConst& rc, uint32_t key, uint32_t dim) { return rc.sampler_debug ? 0.5f : jp_rng_float(key, dim); }
 
 #define FLAG_BOUNCE(f) ((f) & 0xff)
 #define FLAG_SPEC(f)   (((f) >> 8) & 1)
@@ -196,7 +201,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_raygen(SceneView sc, Queues q, Ren
 			const int pix = slot % rc.npix, s = rc.s0 + slot / rc.npix;
 			int x, y; pixel_of(rc, pix, x, y);
 			const uint32_t key = jp_rng_key(rc.seed, (uint32_t)x, (uint32_t)y, (uint32_t)s);
-			const float fx = (float)x + jp_rng_float(key, 0), fy = (float)y + jp_rng_float(key, 1);
+			const float fx = (float)x + rngf(rc, key, 0), fy = (float)y + rngf(rc, key, 1);
 			const V3 front = mk(sc.cam.front[0], sc.cam.front[1], sc.cam.front[2]);
 			const V3 right = mk(sc.cam.right[0], sc.cam.right[1], sc.cam.right[2]);
 			const V3 up = mk(sc.cam.up[0], sc.cam.up[1], sc.cam.up[2]);
@@ -448,7 +453,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				{
 					float up = 0.f;
 					const int mtype = mat_type[mat];
-					if (mtype == JP_MAT_PLASTIC) up = jp_rng_float(key, dim++);   // material.cc:14
+					if (mtype == JP_MAT_PLASTIC) up = rngf(rc, key, dim++);   // material.cc:14
 					make_closure(mats, mtype, mat, up, c);
 #ifdef JP_DBG_SKIP_FRAME
 					fr.n = N; fr.s = mk(N.y, N.z, N.x); fr.t = mk(N.z, N.x, N.y);
@@ -481,7 +486,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 					const unsigned int d0 = dim; dim += 2;                              // the two draws are consumed even when the sample is rejected
 					const float4 lrad = lights[2 * li];
 					if (isblack(xyz(lrad))) continue;                                   // Li would be black (integrator.cc:362): skip the evaluation, keep the draws
-					const float ux = jp_rng_float(key, d0), uy = jp_rng_float(key, d0 + 1);
+					const float ux = rngf(rc, key, d0), uy = rngf(rc, key, d0 + 1);
 					LightSample ls = sample_li(sc, prims, lights, li, p, N, ux, uy);
 					if (isblack(ls.Li) || ls.pdf == 0.f) continue;
 					const V3 f = eval_local(c, wo, to_local(fr, ls.wi));               // FBSDF::Evalf bsdf.h:284-287
@@ -516,7 +521,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 #endif
 		{
 			// ---- BSDF sample (integrator.cc:375-379) ----
-			const float ux = jp_rng_float(key, dim), uy = jp_rng_float(key, dim + 1); dim += 2;
+			const float ux = rngf(rc, key, dim), uy = rngf(rc, key, dim + 1); dim += 2;
 			BsdfSample bs = sample_local(c, wo, ux, uy);
 			bs.wi = to_world(fr, bs.wi);                                              // bsdf.h:295-301
 			if (!(isblack(bs.f) || bs.pdf == 0.f))
@@ -525,7 +530,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				if (bounce >= 3)                                                      // integrator.cc:383-393
 				{
 					const float qq = smax(0.05f, 1 - maxcomp(bs.f));
-					const float ur = jp_rng_float(key, dim++);
+					const float ur = rngf(rc, key, dim++);
 					if (!(ur < qq))
 					{
 						nbeta = cmul(beta, bs.f * absdot(bs.wi, N) / (bs.pdf * (1 - qq)));
@@ -1027,7 +1032,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_other(SceneView sc, Queues q, Rend
 		unsigned int dim = 2;
 		V3 o, d;
 		{
-			const float fx = (float)x + jp_rng_float(key, 0), fy = (float)y + jp_rng_float(key, 1);
+			const float fx = (float)x + rngf(rc, key, 0), fy = (float)y + rngf(rc, key, 1);
 			const V3 front = mk(sc.cam.front[0], sc.cam.front[1], sc.cam.front[2]), right = mk(sc.cam.right[0], sc.cam.right[1], sc.cam.right[2]), up = mk(sc.cam.up[0], sc.cam.up[1], sc.cam.up[2]);
 			o = mk(sc.cam.pos[0], sc.cam.pos[1], sc.cam.pos[2]);
 			d = normalize(front + right * (fx / sc.cam.res_x - 0.5f) + up * (0.5f - fy / sc.cam.res_y));
@@ -1077,7 +1082,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_other(SceneView sc, Queues q, Rend
 				}
 				if (hit < 0) { ret = sc.n_env > 0 ? mk(sc.env_sum.x, sc.env_sum.y, sc.env_sum.z) : mk(0, 0, 0); entering = false; continue; }   // integrator.cc:123-128
 				const int mtype = sc.mat_type[mat];
-				float up = 0.f; if (mtype == JP_MAT_PLASTIC) up = jp_rng_float(key, dim++);
+				float up = 0.f; if (mtype == JP_MAT_PLASTIC) up = rngf(rc, key, dim++);
 				Closure c; make_closure(sc.mats, mtype, mat, up, c);
 				const Frame fr = frame_from_z(N);
 				const V3 wo_w = -d, wo = to_local(fr, wo_w);
@@ -1091,7 +1096,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_other(SceneView sc, Queues q, Rend
 				}
 				for (int li = 0; li < sc.n_lights; li++)                              // integrator.cc:145-158
 				{
-					const float ux = jp_rng_float(key, dim), uy = jp_rng_float(key, dim + 1); dim += 2;
+					const float ux = rngf(rc, key, dim), uy = rngf(rc, key, dim + 1); dim += 2;
 					const float4 lrad = sc.lights[2 * li];
 					LightSample ls = sample_li(sc, sc.prims, sc.lights, li, p, N, ux, uy);
 					if (isblack(ls.Li) || ls.pdf == 0.f) continue;
@@ -1128,7 +1133,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_other(SceneView sc, Queues q, Rend
 						const int want = F.k == 0 ? (4 | 1) : (F.k == 1 ? (4 | 2) : (4 | 1 | 2));   // SpecularReflect / Transmit / ReflectAndTransmit
 						F.k++;
 						if ((flags & want) != flags) continue;                         // MatchTypes bsdf.h:282
-						const float ux = jp_rng_float(key, dim), uy = jp_rng_float(key, dim + 1); dim += 2;
+						const float ux = rngf(rc, key, dim), uy = rngf(rc, key, dim + 1); dim += 2;
 						const Frame fr = frame_from_z(F.N);
 						const V3 wol = to_local(fr, F.wo);
 						closure_set_wo(c, wol);
@@ -1200,6 +1205,27 @@ __global__ void __launch_bounds__(JP_BLOCK) k_tonemap8(const float* __restrict__
 		#pragma unroll
 		for (int step = 128; step > 0; step >>= 1) if (lo + step <= 255 && s_thr[lo + step - 1] <= x) lo += step;
 		rgb8[i] = (unsigned char)lo;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_bsdf: FBSDF::Evalf / Pdf / Sample (bsdf.h:284-302) of a by-value BSDF (jp_xbsdf.h) for n shading events -- behind jp_bsdf
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(JP_BLOCK) k_bsdf(JpBsdfDesc d, int n, const float* nrm, const float* wo, const float* wi, const float* u,
+                                                   float* feval, float* pdfeval, float* sf, float* swi, float* spdf, int* sflags)
+{
+	for (int i = blockIdx.x * JP_BLOCK + threadIdx.x; i < n; i += gridDim.x * JP_BLOCK)
+	{
+		const Frame fr = frame_from_z(mk(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]));
+		const V3 wol = to_local(fr, mk(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2])), wil = to_local(fr, mk(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]));
+		const V3 f = xb::x_eval(d, fr, wol, wil);
+		const float pe = xb::x_pdf(d, fr, wol, wil);
+		BsdfSample s = xb::x_sample(d, fr, wol, u[2 * i], u[2 * i + 1]);
+		s.wi = to_world(fr, s.wi);
+		feval[3 * i] = f.x; feval[3 * i + 1] = f.y; feval[3 * i + 2] = f.z; pdfeval[i] = pe;
+		sf[3 * i] = s.f.x; sf[3 * i + 1] = s.f.y; sf[3 * i + 2] = s.f.z;
+		swi[3 * i] = s.wi.x; swi[3 * i + 1] = s.wi.y; swi[3 * i + 2] = s.wi.z;
+		spdf[i] = s.pdf; sflags[i] = s.flags;
 	}
 }
 
@@ -1936,7 +1962,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 	if (rp->width <= 0 || rp->height <= 0 || rp->spp <= 0 || rp->max_depth < 0 || rp->max_depth > 200) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: bad width/height/spp/max_depth");
 	if (rp->integrator < JP_INTEGRATOR_PATH || rp->integrator > JP_INTEGRATOR_DEBUG_NORMAL) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: unknown integrator");
 	if (rp->integrator == JP_INTEGRATOR_WHITTED && rp->max_depth > JP_WHITTED_MAX_DEPTH) return fail(JP_ERR_UNSUPPORTED, "jp_render: the Whitted integrator supports max_depth <= 16");
-	if (rp->sampler_mode != JP_SAMPLER_COUNTER) return fail(JP_ERR_UNSUPPORTED, "jp_render: the device path implements the counter sampler only (the sequential mt19937_64 stream is not reproducible in parallel)");
+	if (rp->sampler_mode != JP_SAMPLER_COUNTER && rp->sampler_mode != JP_SAMPLER_DEBUG) return fail(JP_ERR_UNSUPPORTED, "jp_render: the device path implements the counter sampler only (the sequential mt19937_64 stream is not reproducible in parallel)");
 	const int band = rp->band_rows > 0 ? rp->band_rows : 20;
 	const int scount = rp->shard_count > 1 ? rp->shard_count : 1;
 	const int sidx = scount > 1 ? rp->shard_index : 0;
@@ -1982,7 +2008,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 
 		RenderConst rc; rc.width = rp->width; rc.height = rp->height; rc.spp = rp->spp; rc.max_depth = rp->max_depth; rc.seed = rp->seed;
 		rc.band_rows = band; rc.shard_index = sidx; rc.shard_count = scount; rc.npix = (int)npix; rc.local_rows = local_rows; rc.n_planes = c->n_planes;
-		rc.lane_index = lane_index; rc.lane_count = lane_count; rc.lane_rows = lane_group; rc.class_mask = c->class_mask;
+		rc.lane_index = lane_index; rc.lane_count = lane_count; rc.lane_rows = lane_group; rc.class_mask = c->class_mask; rc.sampler_debug = rp->sampler_mode == JP_SAMPLER_DEBUG ? 1 : 0;
 		// measured: +6 % on the 280k-triangle scene (cache reuse), -8 % on the LDS-resident Cornell box (coherent waves finish
 		// together or not at all, which unbalances the workgroups) -> tiles only when traversal goes through global memory
 		rc.tiled = (c->trav_mode == 0 && rp->width % 16 == 0 && local_rows % 4 == 0 && !getenv("JETPBRT_NO_TILES")) ? 1 : 0;
@@ -2265,6 +2291,39 @@ int jp_get_build_info(JpContext* c, JpBuildInfo* out)
 	out->built_on_device = c->build_on_device ? 1 : 0; out->traversal_mode = c->trav_mode; out->bvh_nodes = c->bvh_nodes; out->bvh_height = c->bvh_height;
 	out->device_build_ms = c->build_ms; out->libm_sincosf = c->sincosf_mode; out->lanes_last_render = c->last_lanes;
 	return JP_OK;
+}
+
+int jp_bsdf(JpContext* c, const JpBsdfDesc* d, int32_t n, const float* normal, const float* wo, const float* wi, const float* u,
+            float* f_eval, float* pdf_eval, float* s_f, float* s_wi, float* s_pdf, int32_t* s_flags)
+{
+	if (!c || !d || n < 0 || !normal || !wo || !wi || !u || !f_eval || !pdf_eval || !s_f || !s_wi || !s_pdf || !s_flags) return fail(JP_ERR_INVALID_ARGUMENT, "jp_bsdf: null argument");
+	if (d->kind < JP_BSDF_LAMBERT || d->kind > JP_BSDF_PHONG) return fail(JP_ERR_INVALID_ARGUMENT, "jp_bsdf: unknown BSDF kind");
+	if ((d->kind == JP_BSDF_MICROFACET_REFLECTION || d->kind == JP_BSDF_MICROFACET_TRANSMISSION) && (d->distribution < JP_DIST_TROWBRIDGE_REITZ || d->distribution > JP_DIST_BECKMANN))
+		return fail(JP_ERR_INVALID_ARGUMENT, "jp_bsdf: unknown microfacet distribution");
+	if (d->kind == JP_BSDF_MICROFACET_REFLECTION && (d->fresnel < JP_FRESNEL_CONDUCTOR || d->fresnel > JP_FRESNEL_NOOP)) return fail(JP_ERR_INVALID_ARGUMENT, "jp_bsdf: unknown Fresnel term");
+	if (d->kind == JP_BSDF_FRESNEL_SPECULAR && d->eta_a != 1.0f) return fail(JP_ERR_UNSUPPORTED, "jp_bsdf: FFresnelSpecular is implemented for etaI = 1 (FGlassMaterial, material.h:72-75)");
+	if (n == 0) return JP_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	float* din = nullptr; float* dout = nullptr; int* dfl = nullptr;
+	int rc = JP_OK;
+	do
+	{
+		if (hipMalloc((void**)&din, (size_t)n * 11 * 4) != hipSuccess || hipMalloc((void**)&dout, (size_t)n * 11 * 4) != hipSuccess || hipMalloc((void**)&dfl, (size_t)n * 4) != hipSuccess)
+		{ rc = fail(JP_ERR_DEVICE, "jp_bsdf: out of device memory"); break; }
+		float *dn = din, *dwo = din + 3 * (size_t)n, *dwi = din + 6 * (size_t)n, *du = din + 9 * (size_t)n;
+		float *df = dout, *dpe = dout + 3 * (size_t)n, *dsf = dout + 4 * (size_t)n, *dswi = dout + 7 * (size_t)n, *dsp = dout + 10 * (size_t)n;
+		hipMemcpyAsync(dn, normal, (size_t)n * 12, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(dwo, wo, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
+		hipMemcpyAsync(dwi, wi, (size_t)n * 12, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(du, u, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
+		const int grid = std::min(c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK);
+		hipLaunchKernelGGL(k_bsdf, dim3(grid), dim3(JP_BLOCK), 0, c->stream, *d, n, (const float*)dn, (const float*)dwo, (const float*)dwi, (const float*)du, df, dpe, dsf, dswi, dsp, dfl);
+		hipMemcpyAsync(f_eval, df, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream); hipMemcpyAsync(pdf_eval, dpe, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+		hipMemcpyAsync(s_f, dsf, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream); hipMemcpyAsync(s_wi, dswi, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream);
+		hipMemcpyAsync(s_pdf, dsp, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream); hipMemcpyAsync(s_flags, dfl, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+		hipError_t e = hipStreamSynchronize(c->stream);
+		if (e != hipSuccess) rc = fail(JP_ERR_DEVICE, std::string("jp_bsdf: ") + hipGetErrorString(e));
+	} while (0);
+	hipFree(din); hipFree(dout); hipFree(dfl);
+	return rc;
 }
 
 int jp_trace(JpContext* c, int32_t n, const float* origin, const float* dir, const float* tmin, const float* tmax, int32_t* hit, float* t, int32_t* prim, float* normal)

@@ -135,6 +135,38 @@ int jp_host_render_ldr(void* h, int W, int H, int spp, int maxdepth, unsigned se
 	return JP_OK;
 }
 
+// The reference's reflection classes by name (jetpbrt.h "reflection API"): builds the named class the way reference code would and
+// calls Evalf / Pdf / Sample once.  which: 0 FPhongSpecularReflection(Ks, exponent), 1 FMicrofacetReflection(R, Beckmann(ax, ay, vis),
+// FresnelNoOp), 2 FMicrofacetTransmission(T, TrowbridgeReitz(ax, ay, vis), etaA, etaB).  out: f[3], pdf, sample f[3], wi[3], pdf, flags
+int jp_host_bsdf_class(int which, const float* color, float p0, float p1, int vis, float etaA, float etaB, const float* n, const float* wo, const float* wi, const float* u, float* out)
+{
+	FFrame frame(FVector3(n[0], n[1], n[2]));
+	std::unique_ptr<FBSDF> b;
+	const FColor c(color[0], color[1], color[2]);
+	if (which == 0) b.reset(new FPhongSpecularReflection(frame, c, p0));
+	else if (which == 1) b.reset(new FMicrofacetReflection(frame, c, new BeckmannDistribution(p0, p1, vis != 0), new FresnelNoOp()));
+	else if (which == 2) b.reset(new FMicrofacetTransmission(frame, c, new TrowbridgeReitzDistribution(p0, p1, vis != 0), etaA, etaB));
+	else return JP_ERR_INVALID_ARGUMENT;
+	const FVector3 a(wo[0], wo[1], wo[2]), d(wi[0], wi[1], wi[2]);
+	FColor f = b->Evalf(a, d); Float pdf = b->Pdf(a, d); FBSDFSample s = b->Sample(a, FVector2(u[0], u[1]));
+	out[0] = f.r; out[1] = f.g; out[2] = f.b; out[3] = pdf; out[4] = s.f.r; out[5] = s.f.g; out[6] = s.f.b; out[7] = s.wi.x; out[8] = s.wi.y; out[9] = s.wi.z; out[10] = s.pdf; out[11] = (float)s.ebsdf;
+	return JP_OK;
+}
+
+// FGpuPathIntegrator::Render with one of the reference's other samplers: 0 FRandomSampler, 1 FStratifiedSampler, 2 FDebugSampler
+int jp_host_render_sampler(void* h, int sampler, int W, int H, int spp, int maxdepth, int device, float* film_out)
+{
+	HostScene* hs = (HostScene*)h;
+	FGpuPathIntegrator integ(maxdepth, device);
+	FFilm film(W, H);
+	std::unique_ptr<FSampler> s;
+	if (sampler == 2) s.reset(new FDebugSampler(spp)); else if (sampler == 1) s.reset(new FStratifiedSampler(spp)); else s.reset(new FRandomSampler(spp));
+	integ.Render(hs->scene.get(), s.get(), &film, 16);
+	if (integ.LastStatus() != JP_OK) return integ.LastStatus();
+	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const FColor& c = film(x, y); float* o = film_out + 3 * ((size_t)y * W + x); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
+	return JP_OK;
+}
+
 // gamma_encoding (film.h:24) on the host for n values (tests: the device's bytes must equal these)
 void jp_host_gamma_encode(const float* x, int n, unsigned char* out) { for (int i = 0; i < n; i++) out[i] = gamma_encoding(x[i]); }
 

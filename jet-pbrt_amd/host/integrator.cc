@@ -22,6 +22,7 @@ struct HipApi
 	int (*upload_scene)(JpContext*, const JpScene*) = nullptr;
 	int (*render)(JpContext*, const JpRenderParams*, float*) = nullptr;
 	int (*render_rgb8)(JpContext*, const JpRenderParams*, uint8_t*, float*) = nullptr;
+	int (*bsdf)(JpContext*, const JpBsdfDesc*, int32_t, const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*, int32_t*) = nullptr;
 	int (*get_counters)(JpContext*, JpCounters*) = nullptr;
 	std::string error;
 };
@@ -45,11 +46,39 @@ HipApi& Api()
 		api.render = (int (*)(JpContext*, const JpRenderParams*, float*))dlsym(api.lib, "jp_render");
 		api.get_counters = (int (*)(JpContext*, JpCounters*))dlsym(api.lib, "jp_get_counters");
 		api.render_rgb8 = (int (*)(JpContext*, const JpRenderParams*, uint8_t*, float*))dlsym(api.lib, "jp_render_rgb8");
-		if (!api.last_error || !api.create_context || !api.destroy_context || !api.upload_scene || !api.render || !api.get_counters || !api.render_rgb8)
+		api.bsdf = (decltype(api.bsdf))dlsym(api.lib, "jp_bsdf");
+		if (!api.last_error || !api.create_context || !api.destroy_context || !api.upload_scene || !api.render || !api.get_counters || !api.render_rgb8 || !api.bsdf)
 		{ api.error = "libjetpbrt_amd.so lacks a required jp_* symbol"; dlclose(api.lib); api.lib = nullptr; }
 	});
 	return api;
 }
+}
+
+// ---- reflection API: one shading event on the device (jp_bsdf), on a context of this process created on first use ----
+namespace
+{
+struct BsdfOut { float f[3], pdf, sf[3], swi[3], spdf; int32_t flags; bool ok; };
+BsdfOut DeviceBsdf(const JpBsdfDesc& d, const FVector3& n, const FVector3& wo, const FVector3& wi, const FVector2& u)
+{
+	static JpContext* bctx = nullptr; static std::mutex mu;
+	BsdfOut o; std::memset(&o, 0, sizeof(o));
+	HipApi& api = Api();
+	if (!api.lib) { fprintf(stderr, "FBSDF: HIP library not available (%s)\n", api.error.c_str()); return o; }
+	std::lock_guard<std::mutex> lock(mu);
+	if (!bctx && api.create_context(0, &bctx) != JP_OK) { fprintf(stderr, "FBSDF: %s\n", api.last_error()); bctx = nullptr; return o; }
+	const float nn[3] = { n.x, n.y, n.z }, a[3] = { wo.x, wo.y, wo.z }, b[3] = { wi.x, wi.y, wi.z }, uu[2] = { u.x, u.y };
+	if (api.bsdf(bctx, &d, 1, nn, a, b, uu, o.f, &o.pdf, o.sf, o.swi, &o.spdf, &o.flags) != JP_OK) { fprintf(stderr, "FBSDF: %s\n", api.last_error()); return o; }
+	o.ok = true;
+	return o;
+}
+}
+FColor FBSDF::Evalf(const FVector3& wo, const FVector3& wi) const { BsdfOut o = DeviceBsdf(desc, normal, wo, wi, FVector2(0.5f, 0.5f)); return FColor(o.f[0], o.f[1], o.f[2]); }
+Float FBSDF::Pdf(const FVector3& wo, const FVector3& wi) const { return DeviceBsdf(desc, normal, wo, wi, FVector2(0.5f, 0.5f)).pdf; }
+FBSDFSample FBSDF::Sample(const FVector3& wo, const FVector2& random) const
+{
+	BsdfOut o = DeviceBsdf(desc, normal, wo, wo, random);
+	FBSDFSample s; s.f = FColor(o.sf[0], o.sf[1], o.sf[2]); s.wi = FVector3(o.swi[0], o.swi[1], o.swi[2]); s.pdf = o.spdf; s.ebsdf = o.flags;
+	return s;
 }
 
 FGpuPathIntegrator::FGpuPathIntegrator(int maxDepth, int deviceId) : maxDepth(maxDepth), deviceId(deviceId) { std::memset(&counters, 0, sizeof(counters)); }
@@ -88,7 +117,7 @@ void FGpuPathIntegrator::Render(const FScene* scene, FSampler* sampler, FFilm* f
 	JpRenderParams rp; std::memset(&rp, 0, sizeof(rp));
 	rp.width = film->Width(); rp.height = film->Height();
 	rp.spp = sampler->GetSamplesPerPixel(); rp.max_depth = maxDepth;
-	rp.sampler_mode = JP_SAMPLER_COUNTER; rp.seed = sampler->Seed();
+	rp.sampler_mode = sampler->Mode(); rp.seed = sampler->Seed();
 	rp.band_rows = bandRows; rp.shard_index = shardIndex; rp.shard_count = shardCount; rp.integrator = kind;
 	const bool floatFilm = !(film->wantLDR && film->ldrOnly);
 	std::vector<float> rgb(floatFilm ? (size_t)rp.width * rp.height * 3 : 0);

@@ -191,6 +191,7 @@ public:
 	virtual int GetSamplesPerPixel() { return samples_per_pixel; }
 	virtual void SetSamplesPerPixel(int s) { samples_per_pixel = s; }
 	virtual uint32_t Seed() const = 0;
+	virtual int Mode() const { return JP_SAMPLER_COUNTER; }     // JpRenderParams::sampler_mode
 protected:
 	int samples_per_pixel;
 };
@@ -202,6 +203,13 @@ class FCounterSampler : public FSampler
 // "random sampler" is served by the counter stream with the stock seed 1234 (sampler.h:26): same
 // distribution, different random numbers.
 class FRandomSampler : public FCounterSampler { public: FRandomSampler(int spp) : FCounterSampler(spp, 1234) {} };
+// sampler.h:160-185: the reference's stratified sampler is an unfinished copy of its random sampler ("TODO") -- the same here
+class FStratifiedSampler : public FCounterSampler { public: FStratifiedSampler(int spp) : FCounterSampler(spp, 1234) {} };
+// sampler.h:109-127: every draw is 0.5 and the camera sample is the pixel centre (the reference's GetCameraSample computes
+// posfilm + (0.5, 0.5) but lacks its return statement); served by the device's JP_SAMPLER_DEBUG mode
+class FDebugSampler : public FSampler
+{ public: FDebugSampler(int spp) : FSampler(spp) {} std::unique_ptr<FSampler> Clone() override { return std::make_unique<FDebugSampler>(samples_per_pixel); }
+  uint32_t Seed() const override { return 0; } int Mode() const override { return JP_SAMPLER_DEBUG; } };
 
 class FCamera                                                    // camera.h:32-70
 {
@@ -235,6 +243,60 @@ public:
 	int width, height; std::vector<FColor> pixels;
 	bool wantLDR = false, ldrOnly = false; std::vector<uint8_t> ldr8;   // R G B per pixel, top row first
 };
+
+// ---- reflection API (bsdf.h, bsdf.cc, microfacet.h, microfacet.cc) --------------------------------------------------------
+// The reference's BSDF classes by name, for code that builds or probes a BSDF directly (the render path builds its closures on the
+// device from the material table).  Objects only hold their parameters; Evalf / Pdf / Sample run ON THE DEVICE through jp_bsdf
+// (k_bsdf, csrc/jp_xbsdf.h) -- there is no host implementation.  World-space vectors, frame = FFrame(normal) as in bsdf.h:284-302.
+struct FFrame { FVector3 n; FFrame(const FVector3& nn) : n(nn) {} };                     // geometry.h:326-378 (built on the device)
+struct FBSDFSample { FColor f; FVector3 wi; Float pdf = 0; int ebsdf = 0; };             // bsdf.h:252-265
+class Fresnel { public: virtual ~Fresnel() {} virtual void Fill(JpBsdfDesc& d) const = 0; };               // bsdf.h:637-643
+class FresnelConductor : public Fresnel                                                   // bsdf.h:645-655
+{ public: FresnelConductor(const FColor& etaI, const FColor& etaT, const FColor& k) : etaI(etaI), etaT(etaT), k(k) {}
+  void Fill(JpBsdfDesc& d) const override { d.fresnel = JP_FRESNEL_CONDUCTOR; d.fr_eta_i[0] = etaI.r; d.fr_eta_i[1] = etaI.g; d.fr_eta_i[2] = etaI.b; d.fr_eta_t[0] = etaT.r; d.fr_eta_t[1] = etaT.g; d.fr_eta_t[2] = etaT.b; d.fr_k[0] = k.r; d.fr_k[1] = k.g; d.fr_k[2] = k.b; }
+  FColor etaI, etaT, k; };
+class FresnelDielectric : public Fresnel                                                  // bsdf.h:657-662
+{ public: FresnelDielectric(Float etaI, Float etaT) : etaI(etaI), etaT(etaT) {}
+  void Fill(JpBsdfDesc& d) const override { d.fresnel = JP_FRESNEL_DIELECTRIC; d.fr_eta_i[0] = d.fr_eta_i[1] = d.fr_eta_i[2] = etaI; d.fr_eta_t[0] = d.fr_eta_t[1] = d.fr_eta_t[2] = etaT; }
+  Float etaI, etaT; };
+class FresnelNoOp : public Fresnel { public: void Fill(JpBsdfDesc& d) const override { d.fresnel = JP_FRESNEL_NOOP; } };   // bsdf.h:664-667
+class MicrofacetDistribution                                                              // microfacet.h:16-39
+{ public: virtual ~MicrofacetDistribution() {} MicrofacetDistribution(int kind, Float ax, Float ay, bool vis) : kind(kind), alphax(ax), alphay(ay), sampleVisibleArea(vis) {}
+  int kind; Float alphax, alphay; bool sampleVisibleArea; };
+class BeckmannDistribution : public MicrofacetDistribution                               // microfacet.h:42-63
+{ public: BeckmannDistribution(Float ax, Float ay, bool samplevis = true) : MicrofacetDistribution(JP_DIST_BECKMANN, ax, ay, samplevis) {}
+  static Float RoughnessToAlpha(Float roughness) { roughness = roughness < (Float)1e-3 ? (Float)1e-3 : roughness; Float x = std::log(roughness); return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x; } };
+class TrowbridgeReitzDistribution : public MicrofacetDistribution                         // microfacet.h:65-99
+{ public: TrowbridgeReitzDistribution(Float ax, Float ay, bool samplevis = true) : MicrofacetDistribution(JP_DIST_TROWBRIDGE_REITZ, ax, ay, samplevis) {}
+  static Float RoughnessToAlpha(Float roughness) { return BeckmannDistribution::RoughnessToAlpha(roughness); } };
+class FBSDF                                                                               // bsdf.h:268-332
+{
+public:
+	virtual ~FBSDF() {}
+	FBSDF(const FFrame& frame, int kind) : normal(frame.n) { desc = JpBsdfDesc(); desc.kind = kind; desc.color[0] = desc.color[1] = desc.color[2] = 1; desc.eta_a = 1; desc.eta_b = 1; desc.sample_visible = 1; }
+	virtual bool IsDelta() const { return desc.kind == JP_BSDF_MIRROR || desc.kind == JP_BSDF_FRESNEL_SPECULAR; }
+	FColor Evalf(const FVector3& world_wo, const FVector3& world_wi) const;
+	Float Pdf(const FVector3& world_wo, const FVector3& world_wi) const;
+	FBSDFSample Sample(const FVector3& world_wo, const FVector2& random) const;
+	JpBsdfDesc desc; FVector3 normal;
+protected:
+	void SetColor(const FColor& c) { desc.color[0] = c.r; desc.color[1] = c.g; desc.color[2] = c.b; }
+	void SetDist(const MicrofacetDistribution* d) { desc.distribution = d->kind; desc.alpha_x = d->alphax; desc.alpha_y = d->alphay; desc.sample_visible = d->sampleVisibleArea ? 1 : 0; }
+};
+class FLambertionReflection : public FBSDF { public: FLambertionReflection(const FFrame& f, const FColor& albedo) : FBSDF(f, JP_BSDF_LAMBERT) { SetColor(albedo); } };   // bsdf.h:336-385
+class FSpecularReflection : public FBSDF { public: FSpecularReflection(const FFrame& f, const FColor& R) : FBSDF(f, JP_BSDF_MIRROR) { SetColor(R); } };                 // bsdf.h:394-435
+class FFresnelSpecular : public FBSDF                                                     // bsdf.h:455-552
+{ public: FFresnelSpecular(const FFrame& f, Float eta_i, Float eta_t, const FColor& Kr, const FColor& Kt) : FBSDF(f, JP_BSDF_FRESNEL_SPECULAR) { SetColor(Kr); desc.color2[0] = Kt.r; desc.color2[1] = Kt.g; desc.color2[2] = Kt.b; desc.eta_a = eta_i; desc.eta_b = eta_t; } };
+class FPhongSpecularReflection : public FBSDF                                             // bsdf.h:557-633
+{ public: FPhongSpecularReflection(const FFrame& f, const FColor& Ks, Float exponent) : FBSDF(f, JP_BSDF_PHONG) { SetColor(Ks); desc.exponent = exponent; } };
+class FMicrofacetReflection : public FBSDF                                                // bsdf.h:676-701, bsdf.cc:29-78 (owns both objects, as the reference does)
+{ public: FMicrofacetReflection(const FFrame& f, const FColor& R, MicrofacetDistribution* distribution, Fresnel* fresnel) : FBSDF(f, JP_BSDF_MICROFACET_REFLECTION), distribution(distribution), fresnel(fresnel) { SetColor(R); SetDist(distribution); fresnel->Fill(desc); }
+  ~FMicrofacetReflection() { delete distribution; delete fresnel; }
+  const MicrofacetDistribution* distribution; const Fresnel* fresnel; };
+class FMicrofacetTransmission : public FBSDF                                              // bsdf.h:703-734, bsdf.cc:80-145
+{ public: FMicrofacetTransmission(const FFrame& f, const FColor& T, MicrofacetDistribution* distribution, Float etaA, Float etaB) : FBSDF(f, JP_BSDF_MICROFACET_TRANSMISSION), distribution(distribution) { SetColor(T); SetDist(distribution); desc.eta_a = etaA; desc.eta_b = etaB; }
+  ~FMicrofacetTransmission() { delete distribution; }
+  const MicrofacetDistribution* distribution; };
 
 // ---- scene ----------------------------------------------------------------------------------------------------
 struct FlatBVH { std::vector<float> bounds; std::vector<int32_t> left, right, prim_index; };

@@ -104,9 +104,10 @@ struct Sampler
 	// libstdc++ uniform_real_distribution<float>(0,1) over mt19937_64: one engine draw, float(u64) / 2^64,
 	// clamped below 1 (std::generate_canonical); SURVEY.md section 8c "RNG facts pinned by probe"
 	float stock() { float r = (float)mt.next() / 18446744073709551616.0f; if (r >= 1.0f) r = std::nextafter(1.0f, 0.0f); return r; }
-	float get1() { return mode == JP_SAMPLER_STOCK_MT19937 ? stock() : jp_rng_float(key, dim++); }                  // sampler.h:140-142
+	float get1() { if (mode == JP_SAMPLER_DEBUG) return 0.5f; return mode == JP_SAMPLER_STOCK_MT19937 ? stock() : jp_rng_float(key, dim++); }   // FDebugSampler sampler.h:118                  // sampler.h:140-142
 	void get2(float& x, float& y)                                                                                 // sampler.h:144-146, 49-52
 	{
+		if (mode == JP_SAMPLER_DEBUG) { x = y = 0.5f; return; }                // FDebugSampler sampler.h:119
 		if (mode == JP_SAMPLER_STOCK_MT19937) { y = stock(); x = stock(); }   // g++ evaluates the 2nd ctor argument first
 		else { x = jp_rng_float(key, dim++); y = jp_rng_float(key, dim++); }
 	}
@@ -666,6 +667,331 @@ inline V3 bsdf_eval(const Closure& c, V3 wo_w, V3 wi_w) { return eval_local(c, t
 inline BsdfSample bsdf_sample(const Closure& c, V3 wo_w, float ux, float uy)                                                         // bsdf.h:295-301
 { BsdfSample s = sample_local(c, to_local(c.frame, wo_w), ux, uy); s.wi = to_world(c.frame, s.wi); return s; }
 
+// ---------------------------------------------------------------------------------------------
+// The rest of the reflection API, by value (JpBsdfDesc): the classes no material instantiates -- FPhongSpecularReflection
+// bsdf.h:557-633, BeckmannDistribution microfacet.cc:11-254 (both sampling branches), TrowbridgeReitzDistribution's
+// non-visible-area branch microfacet.cc:326-350, FMicrofacetTransmission bsdf.cc:80-145, FresnelNoOp bsdf.h:664-667, general
+// FresnelConductor / FresnelDielectric parameters -- next to the ones the materials use.  Plain restatement, libm calls where the
+// reference has them (logf / expf / powf / acosf / atanf / tanf / sinf / cosf through the float overloads of <cmath>).
+// Pinned bit-exact against the compiled reference by tests/golden/kat_bsdf.npz (ref_driver.cc: ref_bsdf_direct).
+// ---------------------------------------------------------------------------------------------
+namespace xb
+{
+const float kInv2Pi = (float)1.0 / ((float)2.0 * kPi);                       // pbrt.h:40,45
+struct Dist { int kind; float ax, ay; bool vis; };
+inline float cos2phi(V3 w) { return cosphi(w) * cosphi(w); }                 // bsdf.h:50-52
+inline float sin2phi(V3 w) { return sinphi(w) * sinphi(w); }
+inline Dist make_dist(const JpBsdfDesc& d) { Dist r; r.kind = d.distribution; r.ax = smax(0.001f, d.alpha_x); r.ay = smax(0.001f, d.alpha_y); r.vis = d.sample_visible != 0; return r; }   // microfacet.h:66-69, 82-85
+
+inline float ErfInv(float x)                                                 // microfacet.cc:11-41
+{
+	float w, p;
+	x = clampf(x, -.99999f, .99999f);
+	w = -std::log((1 - x) * (1 + x));
+	if (w < 5)
+	{
+		w = w - 2.5f;
+		p = 2.81022636e-08f; p = 3.43273939e-07f + p * w; p = -3.5233877e-06f + p * w; p = -4.39150654e-06f + p * w; p = 0.00021858087f + p * w;
+		p = -0.00125372503f + p * w; p = -0.00417768164f + p * w; p = 0.246640727f + p * w; p = 1.50140941f + p * w;
+	}
+	else
+	{
+		w = std::sqrt(w) - 3;
+		p = -0.000200214257f; p = 0.000100950558f + p * w; p = 0.00134934322f + p * w; p = -0.00367342844f + p * w; p = 0.00573950773f + p * w;
+		p = -0.0076224613f + p * w; p = 0.00943887047f + p * w; p = 1.00167406f + p * w; p = 2.83297682f + p * w;
+	}
+	return p * x;
+}
+inline float Erf(float x)                                                    // microfacet.cc:43-64
+{
+	float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+	int sign = 1;
+	if (x < 0) sign = -1;
+	x = std::abs(x);
+	float t = 1 / (1 + p * x);
+	float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
+	return sign * y;
+}
+inline void BeckmannSample11(float cosThetaI, float U1, float U2, float* slope_x, float* slope_y)   // microfacet.cc:67-144
+{
+	if (cosThetaI > .9999f)
+	{
+		float r = std::sqrt(-std::log(1.0f - U1));
+		float sinPhi = std::sin(2 * kPi * U2);
+		float cosPhi = std::cos(2 * kPi * U2);
+		*slope_x = r * cosPhi; *slope_y = r * sinPhi;
+		return;
+	}
+	float sinThetaI = std::sqrt(smax((float)0, (float)1 - cosThetaI * cosThetaI));
+	float tanThetaI = sinThetaI / cosThetaI;
+	float cotThetaI = 1 / tanThetaI;
+	float a = -1, c = Erf(cotThetaI);
+	float sample_x = smax(U1, (float)1e-6f);
+	float thetaI = std::acos(cosThetaI);
+	float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+	float b = c - (1 + c) * std::pow(1 - sample_x, fit);
+	static const float SQRT_PI_INV = 1.f / std::sqrt(kPi);
+	float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * std::exp(-cotThetaI * cotThetaI));
+	int it = 0;
+	while (++it < 10)
+	{
+		if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+		float invErf = ErfInv(b);
+		float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * std::exp(-invErf * invErf)) - sample_x;
+		float derivative = normalization * (1 - invErf * tanThetaI);
+		if (std::abs(value) < 1e-5f) break;
+		if (value > 0) c = b; else a = b;
+		b -= value / derivative;
+	}
+	*slope_x = ErfInv(b);
+	*slope_y = ErfInv(2.0f * smax(U2, (float)1e-6f) - 1.0f);
+}
+inline V3 stretch_sample(const Dist& D, V3 wi, float U1, float U2)           // BeckmannSample microfacet.cc:146-170 / TrowbridgeReitzSample :303-324
+{
+	V3 ws = normalize(mk(D.ax * wi.x, D.ay * wi.y, wi.z));
+	float sx, sy;
+	if (D.kind == JP_DIST_BECKMANN) BeckmannSample11(ws.z, U1, U2, &sx, &sy); else tr_sample11(ws.z, U1, U2, &sx, &sy);
+	float tmp = cosphi(ws) * sx - sinphi(ws) * sy;
+	sy = sinphi(ws) * sx + cosphi(ws) * sy;
+	sx = tmp;
+	sx = D.ax * sx; sy = D.ay * sy;
+	return normalize(mk(-sx, -sy, 1.f));
+}
+inline float dist_D(const Dist& D, V3 wh)                                    // microfacet.cc:175-192
+{
+	float tan2Theta = tan2t(wh);
+	if (std::isinf(tan2Theta)) return 0.;
+	const float cos4Theta = (wh.z * wh.z) * (wh.z * wh.z);
+	if (D.kind == JP_DIST_BECKMANN)
+		return std::exp(-tan2Theta * (cos2phi(wh) / (D.ax * D.ax) + sin2phi(wh) / (D.ay * D.ay))) / (kPi * D.ax * D.ay * cos4Theta);
+	float e = (cos2phi(wh) / (D.ax * D.ax) + sin2phi(wh) / (D.ay * D.ay)) * tan2Theta;
+	return 1 / (kPi * D.ax * D.ay * cos4Theta * (1 + e) * (1 + e));
+}
+inline float dist_Lambda(const Dist& D, V3 w)                                // microfacet.cc:194-214
+{
+	float absTanTheta = std::abs(tant(w));
+	if (std::isinf(absTanTheta)) return 0.;
+	float alpha = std::sqrt(cos2phi(w) * D.ax * D.ax + sin2phi(w) * D.ay * D.ay);
+	if (D.kind == JP_DIST_BECKMANN)
+	{
+		float a = 1 / (alpha * absTanTheta);
+		if (a >= 1.6f) return 0;
+		return (1 - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
+	}
+	float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
+	return (-1 + std::sqrt(1.f + alpha2Tan2Theta)) / 2;
+}
+inline float dist_G1(const Dist& D, V3 w) { return 1 / (1 + dist_Lambda(D, w)); }                             // microfacet.h:22-25
+inline float dist_G(const Dist& D, V3 wo, V3 wi) { return 1 / (1 + dist_Lambda(D, wo) + dist_Lambda(D, wi)); } // microfacet.h:26-28
+inline float dist_Pdf(const Dist& D, V3 wo, V3 wh)                           // microfacet.cc:359-365
+{
+	if (D.vis) return dist_D(D, wh) * dist_G1(D, wo) * absdot(wo, wh) / std::abs(wo.z);
+	return dist_D(D, wh) * std::abs(wh.z);
+}
+inline V3 spherical(float sinTheta, float cosTheta, float phi) { return mk(sinTheta * std::cos(phi), sinTheta * std::sin(phi), cosTheta); }   // geometry.h:203-209
+inline V3 dist_sample_wh(const Dist& D, V3 wo, float u0, float u1)           // microfacet.cc:216-254 (Beckmann), :326-357 (TrowbridgeReitz)
+{
+	if (D.vis)
+	{
+		bool flip = wo.z < 0;
+		V3 wh = stretch_sample(D, flip ? -wo : wo, u0, u1);
+		if (flip) wh = -wh;
+		return wh;
+	}
+	V3 wh;
+	if (D.kind == JP_DIST_BECKMANN)
+	{
+		float tan2Theta, phi;
+		if (D.ax == D.ay)
+		{
+			float logSample = std::log(1 - u0);
+			tan2Theta = -D.ax * D.ax * logSample;
+			phi = u1 * 2 * kPi;
+		}
+		else
+		{
+			float logSample = std::log(1 - u0);
+			phi = std::atan(D.ay / D.ax * std::tan(2 * kPi * u1 + 0.5f * kPi));
+			if (u1 > 0.5f) phi += kPi;
+			float sinPhi = std::sin(phi), cosPhi = std::cos(phi);
+			float ax2 = D.ax * D.ax, ay2 = D.ay * D.ay;
+			tan2Theta = -logSample / (cosPhi * cosPhi / ax2 + sinPhi * sinPhi / ay2);
+		}
+		float cosTheta = 1 / std::sqrt(1 + tan2Theta);
+		float sinTheta = std::sqrt(smax((float)0, 1 - cosTheta * cosTheta));
+		wh = spherical(sinTheta, cosTheta, phi);
+	}
+	else
+	{
+		float cosTheta = 0, phi = (2 * kPi) * u1;
+		if (D.ax == D.ay)
+		{
+			float tanTheta2 = D.ax * D.ax * u0 / (1.0f - u0);
+			cosTheta = 1 / std::sqrt(1 + tanTheta2);
+		}
+		else
+		{
+			phi = std::atan(D.ay / D.ax * std::tan(2 * kPi * u1 + .5f * kPi));
+			if (u1 > .5f) phi += kPi;
+			float sinPhi = std::sin(phi), cosPhi = std::cos(phi);
+			const float ax2 = D.ax * D.ax, ay2 = D.ay * D.ay;
+			const float alpha2 = 1 / (cosPhi * cosPhi / ax2 + sinPhi * sinPhi / ay2);
+			float tanTheta2 = alpha2 * u0 / (1 - u0);
+			cosTheta = 1 / std::sqrt(1 + tanTheta2);
+		}
+		float sinTheta = std::sqrt(smax((float)0., (float)1. - cosTheta * cosTheta));
+		wh = spherical(sinTheta, cosTheta, phi);
+	}
+	if (!same_hemi(wo, wh)) wh = -wh;
+	return wh;
+}
+inline V3 fresnel_of(const JpBsdfDesc& d, float cosI)                        // bsdf.cc:15-24, bsdf.h:664-667
+{
+	if (d.fresnel == JP_FRESNEL_NOOP) return splat(1.f);
+	if (d.fresnel == JP_FRESNEL_DIELECTRIC) return splat(fresnel_dielectric(cosI, d.fr_eta_i[0], d.fr_eta_t[0]));
+	return fresnel_conductor(std::abs(cosI), ld3(d.fr_eta_i), ld3(d.fr_eta_t), ld3(d.fr_k));
+}
+
+struct Out { V3 f; float pdf; };
+// Evalf_Local / Pdf_Local
+inline V3 x_eval(const JpBsdfDesc& d, const Frame& fr, V3 wo, V3 wi);
+inline float x_pdf(const JpBsdfDesc& d, const Frame& fr, V3 wo, V3 wi)
+{
+	switch (d.kind)
+	{
+	case JP_BSDF_LAMBERT: return same_hemi(wo, wi) ? std::abs(wi.z) * kInvPi : 0;                    // bsdf.h:357-360
+	case JP_BSDF_MICROFACET_REFLECTION:                                                              // bsdf.cc:53-58
+	{
+		if (!same_hemi(wo, wi)) return 0;
+		Dist D = make_dist(d);
+		V3 wh = normalize(wo + wi);
+		return dist_Pdf(D, wo, wh) / (4 * dot(wo, wh));
+	}
+	case JP_BSDF_MICROFACET_TRANSMISSION:                                                            // bsdf.cc:110-124
+	{
+		if (same_hemi(wo, wi)) return 0;
+		Dist D = make_dist(d);
+		float eta = wo.z > 0 ? (d.eta_b / d.eta_a) : (d.eta_a / d.eta_b);
+		V3 wh = normalize(wo + wi * eta);
+		if (dot(wo, wh) * dot(wi, wh) > 0) return 0;
+		float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+		float dwh_dwi = std::abs((eta * eta * dot(wi, wh)) / (sqrtDenom * sqrtDenom));
+		return dist_Pdf(D, wo, wh) * dwh_dwi;
+	}
+	case JP_BSDF_PHONG:                                                                              // bsdf.h:584-590, 622-626
+	{
+		const V3 wr = reflect(wo, mk(0, 0, 1));
+		const float cosTheta = smax((float)0, dot(wr, wi));
+		return (d.exponent + 1) * std::pow(cosTheta, d.exponent) * kInv2Pi;
+	}
+	default: return 0;                                                                               // delta BSDFs bsdf.h:410-413, 473-476
+	}
+}
+inline V3 x_eval(const JpBsdfDesc& d, const Frame& fr, V3 wo, V3 wi)
+{
+	switch (d.kind)
+	{
+	case JP_BSDF_LAMBERT: return same_hemi(wo, wi) ? ld3(d.color) * kInvPi : splat(0);
+	case JP_BSDF_MICROFACET_REFLECTION:                                                              // bsdf.cc:35-51
+	{
+		Dist D = make_dist(d);
+		float cosO = std::abs(wo.z), cosI = std::abs(wi.z);
+		V3 wh = wi + wo;
+		if (cosI == 0 || cosO == 0) return splat(0);
+		if (wh.x == 0 && wh.y == 0 && wh.z == 0) return splat(0);
+		wh = normalize(wh);
+		V3 ff = (dot(wh, mk(0, 0, 1)) < 0) ? -wh : wh;
+		V3 F = fresnel_of(d, dot(wi, ff));
+		return cmul(ld3(d.color) * dist_D(D, wh) * dist_G(D, wo, wi), F) / (4 * cosI * cosO);
+	}
+	case JP_BSDF_MICROFACET_TRANSMISSION:                                                            // bsdf.cc:85-108
+	{
+		if (same_hemi(wo, wi)) return splat(0);
+		Dist D = make_dist(d);
+		float cosO = wo.z, cosI = wi.z;
+		if (cosI == 0 || cosO == 0) return splat(0);
+		float eta = wo.z > 0 ? (d.eta_b / d.eta_a) : (d.eta_a / d.eta_b);
+		V3 wh = normalize(wo + wi * eta);
+		if (wh.z < 0) wh = -wh;
+		if (dot(wo, wh) * dot(wi, wh) > 0) return splat(0);
+		V3 F = splat(fresnel_dielectric(dot(wo, wh), d.eta_a, d.eta_b));
+		float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+		float factor = (1 / eta);
+		return cmul(splat(1) - F, ld3(d.color)) *
+			std::abs(dist_D(D, wh) * dist_G(D, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor / (cosI * cosO * sqrtDenom * sqrtDenom));
+	}
+	case JP_BSDF_PHONG:                                                                              // bsdf.h:571-582
+	{
+		if (!same_hemi(wo, wi)) return splat(0);
+		const V3 wr = reflect(wo, mk(0, 0, 1));
+		const float cos_alpha = dot(wr, wi);
+		const V3 rho = ld3(d.color) * (d.exponent + 2.f) * kInv2Pi;
+		return rho * std::pow(cos_alpha, d.exponent);
+	}
+	default: return splat(0);
+	}
+}
+inline BsdfSample x_sample(const JpBsdfDesc& d, const Frame& fr, V3 wo, float ux, float uy)
+{
+	BsdfSample s = empty_sample();
+	switch (d.kind)
+	{
+	case JP_BSDF_LAMBERT: case JP_BSDF_MIRROR: case JP_BSDF_FRESNEL_SPECULAR:
+	{   // the closures the materials build: the path's own code
+		Closure c; c.frame = fr; c.c0 = ld3(d.color); c.c1 = ld3(d.color2); c.eta_i = d.eta_a; c.eta_t = d.eta_b; c.ax = c.ay = 0; c.fresnel = FR_CONDUCTOR; c.feta = c.fk = splat(0);
+		c.kind = d.kind == JP_BSDF_LAMBERT ? CL_LAMBERT : (d.kind == JP_BSDF_MIRROR ? CL_MIRROR : CL_FRESNEL_SPECULAR);
+		return sample_local(c, wo, ux, uy);
+	}
+	case JP_BSDF_MICROFACET_REFLECTION:                                                              // bsdf.cc:60-78
+	{
+		if (wo.z == 0) return s;
+		Dist D = make_dist(d);
+		V3 wh = dist_sample_wh(D, wo, ux, uy);
+		if (dot(wo, wh) < 0) return s;
+		V3 wi = reflect(wo, wh);
+		if (!same_hemi(wo, wi)) return s;
+		s.wi = wi;
+		s.f = x_eval(d, fr, wo, wi);
+		s.pdf = dist_Pdf(D, wo, wh) / (4 * dot(wo, wh));
+		s.flags = BS_REFLECTION | BS_GLOSSY;
+		return s;
+	}
+	case JP_BSDF_MICROFACET_TRANSMISSION:                                                            // bsdf.cc:126-145
+	{
+		if (wo.z == 0) return s;
+		Dist D = make_dist(d);
+		V3 wh = dist_sample_wh(D, wo, ux, uy);
+		if (dot(wo, wh) < 0) return s;
+		V3 wi;
+		float eta = wo.z > 0 ? (d.eta_a / d.eta_b) : (d.eta_b / d.eta_a);
+		if (!refract(wo, wh, eta, &wi)) return s;
+		s.wi = wi;
+		// bsdf.cc:141 calls FBSDF::Pdf -- the WORLD-space entry (bsdf.h:290-293) -- on the local vectors: they go through ToLocal once more
+		s.pdf = x_pdf(d, fr, to_local(fr, wo), to_local(fr, wi));
+		s.f = x_eval(d, fr, wo, wi);
+		s.flags = BS_TRANSMISSION | BS_GLOSSY;
+		return s;
+	}
+	case JP_BSDF_PHONG:                                                                              // bsdf.h:592-611
+	{
+		const float phi = 2 * kPi * ux;
+		const float cos_theta = std::pow(uy, (float)1 / (d.exponent + 1));
+		const float sin_theta = std::sqrt(1.f - cos_theta * cos_theta);
+		V3 wl = mk(std::cos(phi) * sin_theta, std::sin(phi) * sin_theta, cos_theta);
+		const V3 wr = reflect(wo, mk(0, 0, 1));
+		Frame lobe = frame_from_z(wr);
+		s.wi = to_world(lobe, wl);
+		if (wo.z < 0) s.wi.z *= -1;
+		s.f = x_eval(d, fr, wo, s.wi);
+		s.pdf = x_pdf(d, fr, wo, s.wi);
+		s.flags = BS_REFLECTION | BS_GLOSSY;
+		return s;
+	}
+	}
+	return s;
+}
+} // namespace xb
+
 // FMaterial::Scattering (material.h:34-37, 52-55, 72-75; material.cc:12-43).  Returns false for a null material.
 inline bool scattering(const JpScene* js, int mat, V3 normal, Draw& rnd, Closure& c)
 {
@@ -1155,6 +1481,25 @@ void jp_oracle_bsdf(void* h, int count, int mat, const float* n, const float* wo
 		sf[3 * i] = s.f.x; sf[3 * i + 1] = s.f.y; sf[3 * i + 2] = s.f.z;
 		swi[3 * i] = s.wi.x; swi[3 * i + 1] = s.wi.y; swi[3 * i + 2] = s.wi.z;
 		spdf[i] = s.pdf; sflags[i] = s.flags; isdelta[i] = c.delta() ? 1 : 0;
+	}
+}
+
+// FBSDF::Evalf / Pdf / Sample (bsdf.h:284-302) of a BSDF given by value (JpBsdfDesc), frame = FFrame(normal)
+void jp_oracle_bsdf_direct(const JpBsdfDesc* d, int count, const float* n, const float* wo, const float* wi, const float* u2,
+                           float* feval, float* pdfeval, float* sf, float* swi, float* spdf, int* sflags)
+{
+	for (int i = 0; i < count; i++)
+	{
+		const Frame fr = frame_from_z(ld3(n + 3 * i));
+		const V3 wol = to_local(fr, ld3(wo + 3 * i)), wil = to_local(fr, ld3(wi + 3 * i));
+		V3 f = xb::x_eval(*d, fr, wol, wil);
+		float pe = xb::x_pdf(*d, fr, wol, wil);
+		BsdfSample s = xb::x_sample(*d, fr, wol, u2[2 * i], u2[2 * i + 1]);
+		s.wi = to_world(fr, s.wi);
+		feval[3 * i] = f.x; feval[3 * i + 1] = f.y; feval[3 * i + 2] = f.z; pdfeval[i] = pe;
+		sf[3 * i] = s.f.x; sf[3 * i + 1] = s.f.y; sf[3 * i + 2] = s.f.z;
+		swi[3 * i] = s.wi.x; swi[3 * i + 1] = s.wi.y; swi[3 * i + 2] = s.wi.z;
+		spdf[i] = s.pdf; sflags[i] = s.flags;
 	}
 }
 

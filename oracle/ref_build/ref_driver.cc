@@ -24,6 +24,7 @@
 #include <cstring>
 
 #include "jp_counter_rng.h"   // include/jp_counter_rng.h: the shared counter-based stream (own code)
+#include "jetpbrt_amd.h"      // JpBsdfDesc: the by-value description ref_bsdf_direct builds the reference's BSDF objects from
 
 using namespace pbrt;
 
@@ -372,6 +373,48 @@ int ref_film_save(const float* rgb, int W, int H, const char* filename, int type
 }
 // gamma_encoding (film.h:24) of the reference for n values
 void ref_gamma_encode(const float* x, int n, unsigned char* out) { for (int i = 0; i < n; i++) out[i] = gamma_encoding(x[i]); }
+
+// The reference's BSDF classes constructed directly (the ones no material instantiates included) from a JpBsdfDesc, and FBSDF::Evalf /
+// Pdf / Sample (bsdf.h:284-302) called on them: frame = FFrame(normal)
+static std::unique_ptr<FBSDF> make_bsdf(const JpBsdfDesc& d, const FFrame& frame)
+{
+	auto col = [](const float* p) { return FColor(p[0], p[1], p[2]); };
+	auto dist = [&]() -> MicrofacetDistribution* {
+		if (d.distribution == JP_DIST_BECKMANN) return new BeckmannDistribution(d.alpha_x, d.alpha_y, d.sample_visible != 0);
+		return new TrowbridgeReitzDistribution(d.alpha_x, d.alpha_y, d.sample_visible != 0);
+	};
+	switch (d.kind)
+	{
+	case JP_BSDF_LAMBERT: return std::make_unique<FLambertionReflection>(frame, col(d.color));
+	case JP_BSDF_MIRROR: return std::make_unique<FSpecularReflection>(frame, col(d.color));
+	case JP_BSDF_FRESNEL_SPECULAR: return std::make_unique<FFresnelSpecular>(frame, d.eta_a, d.eta_b, col(d.color), col(d.color2));
+	case JP_BSDF_MICROFACET_REFLECTION:
+	{
+		Fresnel* fr = d.fresnel == JP_FRESNEL_NOOP ? (Fresnel*)new FresnelNoOp() : d.fresnel == JP_FRESNEL_DIELECTRIC ? (Fresnel*)new FresnelDielectric(d.fr_eta_i[0], d.fr_eta_t[0])
+		              : (Fresnel*)new FresnelConductor(col(d.fr_eta_i), col(d.fr_eta_t), col(d.fr_k));
+		return std::make_unique<FMicrofacetReflection>(frame, col(d.color), dist(), fr);
+	}
+	case JP_BSDF_MICROFACET_TRANSMISSION: return std::make_unique<FMicrofacetTransmission>(frame, col(d.color), dist(), d.eta_a, d.eta_b);
+	case JP_BSDF_PHONG: return std::make_unique<FPhongSpecularReflection>(frame, col(d.color), d.exponent);
+	}
+	return nullptr;
+}
+void ref_bsdf_direct(const JpBsdfDesc* d, int count, const float* n, const float* wo, const float* wi, const float* u2,
+                     float* feval, float* pdfeval, float* sf, float* swi, float* spdf, int* sflags)
+{
+	for (int i = 0; i < count; i++)
+	{
+		FFrame frame(V3(n + 3 * i));
+		std::unique_ptr<FBSDF> b = make_bsdf(*d, frame);
+		FColor f = b->Evalf(V3(wo + 3 * i), V3(wi + 3 * i));
+		pdfeval[i] = b->Pdf(V3(wo + 3 * i), V3(wi + 3 * i));
+		FBSDFSample s = b->Sample(V3(wo + 3 * i), FFloat2(u2[2 * i], u2[2 * i + 1]));
+		feval[3 * i] = f.r; feval[3 * i + 1] = f.g; feval[3 * i + 2] = f.b;
+		sf[3 * i] = s.f.r; sf[3 * i + 1] = s.f.g; sf[3 * i + 2] = s.f.b;
+		swi[3 * i] = s.wi.x; swi[3 * i + 1] = s.wi.y; swi[3 * i + 2] = s.wi.z;
+		spdf[i] = s.pdf; sflags[i] = s.ebsdf;
+	}
+}
 
 // FLight::Sample_Li of light `li` (Lights() order) from a surface point p with normal n
 void ref_light_sample(void* h, int count, int li, const float* p, const float* n, const float* u2,

@@ -43,6 +43,7 @@ def oracle_lib():
         L.jp_oracle_light_sample.argtypes = [_vp, C.c_int, C.c_int] + [_vp] * 7
         L.jp_oracle_li_scripted.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]
         L.jp_oracle_stock_stream.argtypes = [C.c_int, _vp]
+        L.jp_oracle_bsdf_direct.argtypes = [C.POINTER(jp.JpBsdfDesc), C.c_int] + [_vp] * 10
         _oracle = L
     return _oracle
 
@@ -86,6 +87,7 @@ def ref_lib():
         L.ref_li_scripted.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]
         L.ref_stock_stream.argtypes = [C.c_int, _vp]
         L.ref_stock_float2.argtypes = [_vp]
+        L.ref_bsdf_direct.argtypes = [C.POINTER(jp.JpBsdfDesc), C.c_int] + [_vp] * 10
         L.ref_film_save.argtypes = [_vp, C.c_int, C.c_int, C.c_char_p, C.c_int]
         L.ref_gamma_encode.argtypes = [_vp, C.c_int, _vp]
         _ref = L
@@ -191,3 +193,51 @@ def libc_srand(seed=1):
     """the reference BVH draws its split axes from libc rand() (bvh.h:61); reset it so that the compiled
     reference and the restatement build the same tree."""
     C.CDLL(None).srand(seed)
+
+
+def bsdf_cases():
+    """the by-value BSDFs of the KAT set (tests/golden/kat_bsdf.npz): every class of bsdf.h / microfacet.h, the ones no material builds included"""
+    D = jp.bsdf_desc
+    return {
+        "lambert": D(jp.JP_BSDF_LAMBERT, color=(0.63, 0.065, 0.05)),
+        "mirror": D(jp.JP_BSDF_MIRROR, color=(0.9, 0.85, 0.8)),
+        "fresnel_specular": D(jp.JP_BSDF_FRESNEL_SPECULAR, color=(0.98, 0.97, 0.96), color2=(0.95, 0.96, 0.97), eta_a=1.0, eta_b=1.5),
+        "phong_20": D(jp.JP_BSDF_PHONG, color=(0.7, 0.6, 0.5), exponent=20.0),
+        "phong_3": D(jp.JP_BSDF_PHONG, color=(0.2, 0.9, 0.4), exponent=3.0),
+        "tr_conductor": D(jp.JP_BSDF_MICROFACET_REFLECTION, color=(1, 1, 1), distribution=0, alpha=(0.2, 0.2), fresnel=0, fr_eta_i=(1, 1, 1), fr_eta_t=(0.18, 0.15, 0.81), fr_k=(0.11, 0.11, 0.11)),
+        "tr_noop_aniso": D(jp.JP_BSDF_MICROFACET_REFLECTION, color=(0.8, 0.7, 0.9), distribution=0, alpha=(0.15, 0.4), fresnel=2),
+        "tr_full_iso": D(jp.JP_BSDF_MICROFACET_REFLECTION, color=(0.8, 0.8, 0.8), distribution=0, alpha=(0.3, 0.3), sample_visible=False, fresnel=1, fr_eta_i=(1.0,) * 3, fr_eta_t=(1.5,) * 3),
+        "tr_full_aniso": D(jp.JP_BSDF_MICROFACET_REFLECTION, color=(0.8, 0.8, 0.8), distribution=0, alpha=(0.1, 0.35), sample_visible=False, fresnel=2),
+        "beck_conductor": D(jp.JP_BSDF_MICROFACET_REFLECTION, color=(1, 1, 1), distribution=1, alpha=(0.25, 0.25), fresnel=0, fr_eta_i=(1.2, 1.1, 1.0), fr_eta_t=(0.2, 0.9, 1.1), fr_k=(3.9, 2.4, 2.2)),
+        "beck_dielectric_aniso": D(jp.JP_BSDF_MICROFACET_REFLECTION, color=(0.9, 0.9, 0.9), distribution=1, alpha=(0.12, 0.3), fresnel=1, fr_eta_i=(1.5,) * 3, fr_eta_t=(1.0,) * 3),
+        "beck_full_iso": D(jp.JP_BSDF_MICROFACET_REFLECTION, color=(0.7, 0.7, 0.7), distribution=1, alpha=(0.2, 0.2), sample_visible=False, fresnel=2),
+        "beck_full_aniso": D(jp.JP_BSDF_MICROFACET_REFLECTION, color=(0.7, 0.7, 0.7), distribution=1, alpha=(0.4, 0.1), sample_visible=False, fresnel=2),
+        "trans_tr": D(jp.JP_BSDF_MICROFACET_TRANSMISSION, color=(0.95, 0.9, 0.85), distribution=0, alpha=(0.2, 0.2), eta_a=1.0, eta_b=1.5),
+        "trans_beck": D(jp.JP_BSDF_MICROFACET_TRANSMISSION, color=(0.9, 0.95, 1.0), distribution=1, alpha=(0.3, 0.15), eta_a=1.0, eta_b=1.33),
+        "trans_tr_full": D(jp.JP_BSDF_MICROFACET_TRANSMISSION, color=(1, 1, 1), distribution=0, alpha=(0.25, 0.25), sample_visible=False, eta_a=1.5, eta_b=1.0),
+    }
+
+
+def bsdf_inputs(n, seed):
+    """shading events: unit normals, wo / wi spread over both hemispheres (a third of the wi on the far side: transmission), grazing and
+    normal incidence included, u in [0, 1)^2 with a few extreme values"""
+    rng = np.random.default_rng(seed)
+    def unit(v): return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    nrm = unit(rng.normal(size=(n, 3)))
+    wo = unit(rng.normal(size=(n, 3))); wi = unit(rng.normal(size=(n, 3)))
+    same = rng.random(n) < 0.66
+    so = np.sign((wo * nrm).sum(1)); si = np.sign((wi * nrm).sum(1))
+    flip = np.where(same, so * si < 0, so * si > 0)
+    wi = np.where(flip[:, None], wi - 2 * (wi * nrm).sum(1, keepdims=True) * nrm, wi).astype(np.float32)
+    wo[:8] = unit(nrm[:8] + 1e-3 * rng.normal(size=(8, 3)))            # normal incidence
+    u = rng.random((n, 2)).astype(np.float32)
+    u[:4] = [[0.0, 0.0], [0.999999, 0.5], [0.5, 0.999999], [1e-7, 0.25]]
+    return nrm, unit(wo), unit(wi), u
+
+
+def run_bsdf(fn, desc, nrm, wo, wi, u):
+    n = nrm.shape[0]
+    out = dict(f=np.zeros((n, 3), np.float32), pdf=np.zeros(n, np.float32), sf=np.zeros((n, 3), np.float32), swi=np.zeros((n, 3), np.float32),
+               spdf=np.zeros(n, np.float32), sflags=np.zeros(n, np.int32))
+    fn(C.byref(desc), n, ptr(nrm), ptr(wo), ptr(wi), ptr(u), ptr(out["f"]), ptr(out["pdf"]), ptr(out["sf"]), ptr(out["swi"]), ptr(out["spdf"]), ptr(out["sflags"]))
+    return out

@@ -886,3 +886,72 @@ def test_device_tone_map_bytes_equal_the_host_gamma_encoding(H, gpu_ctx, tmp_pat
     raw = open(base + ".bmp", "rb").read()
     body = np.frombuffer(raw[54:], np.uint8).reshape(Hh, W, 3)[::-1, :, ::-1]
     assert len(raw) == 54 + W * Hh * 3 and np.array_equal(body, rgb8)
+
+
+def test_reflection_api_by_value_on_the_device(H, gpu_ctx):
+    """every BSDF class of the reference by value through jp_bsdf (k_bsdf, jp_xbsdf.h) against the compiled
+    reference's KATs (tests/golden/kat_bsdf.npz, 16 BSDFs x 384 shading events: Evalf, Pdf, Sample).
+    Tolerance.  The closures the materials build (Lambert, mirror, Fresnel specular, TrowbridgeReitz visible-area reflection) are the
+    render path's own code: BIT-EXACT when the device reproduces the host libm's sinf/cosf.  The classes no material instantiates call
+    logf / expf / powf / acosf / atanf / tanf, which the reference takes from glibc and the device from its own library (1-2 ulp each,
+    not bit-reproducible), and Beckmann's Newton iteration amplifies that: values within 2e-4 relative (+1e-6 absolute), the sampled
+    direction within 2e-4, flags and the zero / non-zero pattern identical except where the reference value itself is within that
+    tolerance of a branch (counted, < 1 % of the events)."""
+    g = np.load(os.path.join(H.GOLDEN, "kat_bsdf.npz"))
+    nrm, wo, wi, u = H.bsdf_inputs(384, 77)
+    exact_kinds = ("lambert", "mirror", "fresnel_specular", "tr_conductor", "tr_noop_aniso")
+    libm = gpu_ctx.build_info_any().libm_sincosf if hasattr(gpu_ctx, "build_info_any") else H.jp.hip_lib().jp_probe_libm_sincosf()
+    for name, desc in H.bsdf_cases().items():
+        r = gpu_ctx.bsdf(desc, nrm, wo, wi, u)
+        bad_events = np.zeros(384, bool)
+        for k in ("f", "pdf", "sf", "swi", "spdf", "sflags"):
+            want = g["%s__%s" % (name, k)]; got = r[k]
+            if k == "sflags":
+                bad_events |= got != want
+                continue
+            if name in exact_kinds and libm != 0:
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%s.%s not bit-exact: %d differ" % (name, k, int((got != want).sum()))
+                continue
+            tol = 2e-4 * np.abs(want) + (2e-4 if k == "swi" else 1e-6)
+            d = np.abs(got.astype(np.float64) - want)
+            ok = (d <= tol) | (np.isnan(got) & np.isnan(want))
+            bad_events |= ~(ok.all(1) if ok.ndim == 2 else ok)
+        assert bad_events.mean() < 0.01, "%s: %d of 384 events outside the tolerance" % (name, int(bad_events.sum()))
+    # error behaviour of the hook
+    bad = H.jp.bsdf_desc(7)
+    with pytest.raises(H.jp.JetPbrtError):
+        gpu_ctx.bsdf(bad, nrm[:4], wo[:4], wi[:4], u[:4])
+    with pytest.raises(H.jp.JetPbrtError):
+        gpu_ctx.bsdf(H.jp.bsdf_desc(H.jp.JP_BSDF_FRESNEL_SPECULAR, eta_a=1.3), nrm[:4], wo[:4], wi[:4], u[:4])
+
+
+def test_host_reflection_classes_and_other_samplers(H, gpu_ctx):
+    """the reference's class names on the host (jetpbrt.h "reflection API": FPhongSpecularReflection, BeckmannDistribution, FresnelNoOp,
+    FMicrofacetTransmission ...; FStratifiedSampler, FDebugSampler sampler.h:109-185) drive the same device code as the C ABI"""
+    L = H.jp.host_lib()
+    nrm, wo, wi, u = H.bsdf_inputs(16, 5)
+    f3 = lambda v: np.ascontiguousarray(v, np.float32).ctypes.data_as(C.POINTER(C.c_float))
+    D = H.jp.bsdf_desc
+    cases = [(0, (0.7, 0.6, 0.5), 20.0, 0.0, 1, 1.0, 1.0, D(H.jp.JP_BSDF_PHONG, color=(0.7, 0.6, 0.5), exponent=20.0)),
+             (1, (0.8, 0.7, 0.9), 0.25, 0.4, 0, 1.0, 1.0, D(H.jp.JP_BSDF_MICROFACET_REFLECTION, color=(0.8, 0.7, 0.9), distribution=1, alpha=(0.25, 0.4), sample_visible=False, fresnel=2)),
+             (2, (0.95, 0.9, 0.85), 0.2, 0.2, 1, 1.0, 1.5, D(H.jp.JP_BSDF_MICROFACET_TRANSMISSION, color=(0.95, 0.9, 0.85), distribution=0, alpha=(0.2, 0.2), eta_a=1.0, eta_b=1.5))]
+    for which, col, p0, p1, vis, ea, eb, desc in cases:
+        r = gpu_ctx.bsdf(desc, nrm, wo, wi, u)
+        for i in range(16):
+            out = np.zeros(12, np.float32)
+            assert L.jp_host_bsdf_class(which, f3(col), p0, p1, vis, ea, eb, f3(nrm[i]), f3(wo[i]), f3(wi[i]), f3(u[i]), f3(out)) == 0
+            want = np.concatenate([r["f"][i], [r["pdf"][i]], r["sf"][i], r["swi"][i], [r["spdf"][i]], [np.float32(r["sflags"][i])]]).astype(np.float32)
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (which, i)
+    # samplers: FStratifiedSampler = the random sampler (as in the reference); FDebugSampler = constant draws, against the oracle
+    W, Hh, spp = 64, 48, 4
+    hb, sp = _scene(H, "cornell", W, Hh)
+    films = []
+    for s in (0, 1, 2):
+        film = np.zeros((Hh, W, 3), np.float32)
+        assert L.jp_host_render_sampler(hb.h, s, W, Hh, spp, 5, 0, film.ctypes.data) == 0
+        films.append(film)
+    assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32)) and not np.array_equal(films[0], films[2])
+    ref, _ = H.oracle_render(sp, H.jp.render_params(W, Hh, spp, 5, 0, H.jp.JP_SAMPLER_DEBUG), 4)
+    assert_film(gpu_ctx, films[2], ref, "cornell")
+    one, _ = H.oracle_render(sp, H.jp.render_params(W, Hh, 1, 5, 0, H.jp.JP_SAMPLER_DEBUG), 4)
+    assert l2(one, ref) < 1e-6                                    # constant draws: every sample of a pixel is the same path

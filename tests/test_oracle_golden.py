@@ -149,3 +149,21 @@ def test_baseline_config0_cpu_plumbing_at_its_size(H, name):
     assert hashlib.sha256(np.ascontiguousarray(film).tobytes()).hexdigest() == g["sha256"]
     assert [cnt.closest_rays, cnt.closest_hits, cnt.shadow_rays, cnt.shadow_occluded] == g["counts"]
     assert 3.3 < cnt.closest_rays / (Wc * Hc * spp) < 3.6                                     # 3.45 closest-hit rays per sample
+
+
+def test_reflection_api_by_value_bit_exact(H):
+    """every BSDF class of bsdf.h / bsdf.cc / microfacet.cc constructed directly -- FPhongSpecularReflection,
+    BeckmannDistribution (both sampling branches), FMicrofacetTransmission (with the world-space Pdf call of bsdf.cc:141 on local
+    vectors), FresnelNoOp, general conductor / dielectric Fresnel terms, next to the closures the materials build -- Evalf / Pdf /
+    Sample of the oracle restatement against the compiled reference's outputs (tests/golden/make_golden_bsdf.py): BIT-EXACT."""
+    g = np.load(os.path.join(H.GOLDEN, "kat_bsdf.npz"))
+    nrm, wo, wi, u = H.bsdf_inputs(384, 77)
+    for k, v in (("in_nrm", nrm), ("in_wo", wo), ("in_wi", wi), ("in_u", u)):
+        assert np.array_equal(v.view(np.uint32), g[k].view(np.uint32)), "input generator drifted: " + k
+    L = H.oracle_lib()
+    for name, desc in H.bsdf_cases().items():
+        r = H.run_bsdf(L.jp_oracle_bsdf_direct, desc, nrm, wo, wi, u)
+        for k, v in r.items():
+            want = g["%s__%s" % (name, k)]
+            same = np.array_equal(v.view(np.uint32), want.view(np.uint32)) if v.dtype == np.float32 else np.array_equal(v, want)
+            assert same, "%s.%s: %d of %d differ, max abs %g" % (name, k, int((v != want).sum()), v.size, float(np.nanmax(np.abs(v.astype(np.float64) - want))))
