@@ -786,226 +786,6 @@ __global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow_sort(SceneView sc, Queue
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Tiny scenes (traversal mode 2): the same two traversal kernels with the rays of a TILE binned by the number of primitive
-// tests they will pay before the primitives are tested ("wavefront-level ray sort").
-//
-// Why: after the wave-uniform box phase a ray of the Cornell box tests 3.3 primitives on average, but the unluckiest lane of
-// a 64-ray wave tests ~10 (tools/flat_stats.py), and the wave runs as long as its unluckiest lane: lane utilisation of the
-// primitive phase 0.33.  Binning the rays of a 1024-ray tile by their test count and handing each wave 64 rays of (nearly)
-// the same count raises that to 0.85-0.93.  The film cannot change: every ray is still tested against exactly the
-// primitives of the boxes it enters, only WHICH lane of WHICH wave does it changes, and every ray's result goes back to
-// the ray's own queue position (hit record) or shadow entry (visibility), so k_shade / the radiance sums see what they saw.
-//
-// Per tile (block-wide): phase 1 -- every thread loads its rays coalesced, runs flat_boxes (all lanes busy, uniform control
-// flow), writes ray + mask to LDS at the ray's own position and takes a rank in the LDS histogram of its key (popcount of
-// the mask, 32 bins, one ds_add_rtn per ray); an exclusive scan of the 32 bins by one half-wave; every thread stores its
-// rays' tile positions at base[key] + rank (a counting sort of the INDICES -- the ray records stay where they are);
-// phase 2 -- wave w takes sorted positions [64 w, 64 w + 64) of each 256-position pass, gathers the ray record from LDS by
-// the stored index and walks its mask.  Four block barriers per tile.
-// ---------------------------------------------------------------------------------------------------------------------
-#define JP_SORT_BINS 32
-// exclusive scan of hist[0..31] into base[0..31] (+ the total in base[32]) by the first half-wave; hist is cleared for the
-// next tile by the same lanes (its only other users, the ds_add of phase 1, are a barrier away on both sides)
-__device__ __forceinline__ void sort_scan(unsigned int* hist, unsigned int* base)
-{
-	if (threadIdx.x < JP_SORT_BINS)
-	{
-		const unsigned int v = hist[threadIdx.x];
-		unsigned int inc = v;
-		#pragma unroll
-		for (int off = 1; off < JP_SORT_BINS; off <<= 1) { const unsigned int t = __shfl_up(inc, off, JP_SORT_BINS); if ((int)threadIdx.x >= off) inc += t; }
-		base[threadIdx.x] = inc - v;
-		if (threadIdx.x == JP_SORT_BINS - 1) base[JP_SORT_BINS] = inc;
-		hist[threadIdx.x] = 0;
-	}
-}
-
-// LDS layout of k_extend_flat:  [prims: 5 * n_prims float4][hist 32][base 36][so: T float4][sd: T float4][idx: T u16]
-template <int kRPT, bool k64>
-__global__ void __launch_bounds__(JP_BLOCK) k_extend_flat(SceneView sc, Queues q, int cur, DevCounters* cnt)
-{
-	typedef typename FlatMask<k64>::type M;
-	constexpr int T = kRPT * JP_BLOCK;
-	float4* prims = s_dyn;
-	unsigned int* hist = (unsigned int*)(prims + 5 * sc.n_prims);
-	unsigned int* base = hist + JP_SORT_BINS;
-	float4* so = (float4*)(base + JP_SORT_BINS + 4);                 // (origin, mask bits 0..31)
-	float4* sd = so + T;                                             // (direction, mask bits 32..63)
-	unsigned short* sidx = (unsigned short*)(sd + T);
-	for (int i = threadIdx.x; i < 4 * sc.n_prims; i += JP_BLOCK) prims[5 * (i >> 2) + (i & 3)] = sc.prims[i];
-	if (threadIdx.x < JP_SORT_BINS) hist[threadIdx.x] = 0;
-	const unsigned int b = blockIdx.x, n = q.blk_q[cur][b], rbase = b * q.R;
-	if (b == 0 && threadIdx.x == 0) { cnt->closest += cnt->n_queue[cur]; cnt->n_queue[cur ^ 1] = 0; cnt->n_shadow = 0; }
-	__syncthreads();
-	unsigned int h = 0;
-	for (unsigned int t0 = 0; t0 < n; t0 += T)
-	{
-		const unsigned int count = n - t0 < (unsigned int)T ? n - t0 : (unsigned int)T;
-		// ---- phase 1: boxes, histogram ----
-		float4 ro[kRPT], rd[kRPT];
-		#pragma unroll
-		for (int r = 0; r < kRPT; r++)
-		{
-			const unsigned int j = r * JP_BLOCK + threadIdx.x;
-			if (j < count) { ro[r] = q.ray_o[cur][rbase + t0 + j]; rd[r] = q.ray_d[cur][rbase + t0 + j]; }
-		}
-		unsigned int kr[kRPT];                                       // key << 16 | rank
-		#pragma unroll
-		for (int r = 0; r < kRPT; r++)
-		{
-			const unsigned int j = r * JP_BLOCK + threadIdx.x;
-			kr[r] = 0;
-			if (j < count)
-			{
-				const M mask = flat_boxes<k64>(sc.flat, sc.n_flat, xyz(ro[r]), xyz(rd[r]), 0.001f, JP_INF);   // FRay defaults geometry.h:399
-				so[j] = make_float4(ro[r].x, ro[r].y, ro[r].z, __uint_as_float((unsigned int)mask));
-				sd[j] = make_float4(rd[r].x, rd[r].y, rd[r].z, __uint_as_float(k64 ? (unsigned int)((u64)mask >> 32) : 0u));
-				const unsigned int key = min(mask_count<k64>(mask), JP_SORT_BINS - 1);
-				kr[r] = (key << 16) | atomicAdd(&hist[key], 1u);
-			}
-		}
-		__syncthreads();
-		sort_scan(hist, base);
-		__syncthreads();
-		#pragma unroll
-		for (int r = 0; r < kRPT; r++)
-		{
-			const unsigned int j = r * JP_BLOCK + threadIdx.x;
-			if (j < count) sidx[base[kr[r] >> 16] + (kr[r] & 0xffffu)] = (unsigned short)j;
-		}
-		__syncthreads();
-		// ---- phase 2: a wave takes 64 consecutive sorted positions ----
-		#pragma unroll 1
-		for (int r = 0; r < kRPT; r++)
-		{
-			const unsigned int pos = r * JP_BLOCK + threadIdx.x;
-			if (pos < count)
-			{
-				const unsigned int j = sidx[pos];
-				const float4 o4 = so[j], d4 = sd[j];
-				M mask = (M)__float_as_uint(o4.w);
-				if (k64) mask |= (M)((u64)__float_as_uint(d4.w) << 32);
-				float tmax = JP_INF;
-				const int hit = flat_prims<false, k64, 5>(mask, prims, xyz(o4), xyz(d4), 0.001f, tmax);
-				q.hit[rbase + t0 + j] = make_float2(tmax, __int_as_float(hit));
-				h += hit >= 0 ? 1u : 0u;
-			}
-		}
-		__syncthreads();                                             // the next tile's phase 1 overwrites so / sd, which any thread may still be gathering from
-	}
-	for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off);
-	if ((threadIdx.x & 63) == 0 && h) atomicAdd(&cnt->closest_hit, (unsigned long long)h);
-}
-
-// k_shadow_flat: FScene::Occluded for the rays of a tile of shadow entries, binned like the closest-hit rays.  A ray that
-// enters no box is visible without a primitive test.  The visibility of every ray goes to LDS; after the tile's rays are
-// done each thread adds the visible contributions of ITS entries to the path's radiance in light order (integrator.cc:367-370),
-// so the sum is the reference's sum and only the contributions that count are read from HBM.
-// LDS: [prims][hist 32][base 36][eo: TE float4][sd: TE * NP float4][sm: TE * NP masks][idx: TE * NP u16][vis: TE * NP u8]
-template <int kEPT, bool k64>
-__global__ void __launch_bounds__(JP_BLOCK) k_shadow_flat(SceneView sc, Queues q, RenderConst rc, DevCounters* cnt)
-{
-	typedef typename FlatMask<k64>::type M;
-	constexpr int TE = kEPT * JP_BLOCK;
-	const int NP = rc.n_planes;
-	float4* prims = s_dyn;
-	unsigned int* hist = (unsigned int*)(prims + 5 * sc.n_prims);
-	unsigned int* base = hist + JP_SORT_BINS;
-	float4* eo = (float4*)(base + JP_SORT_BINS + 4);                 // per entry: (origin, slot | count << 24)
-	float4* sd = eo + TE;                                            // per ray (plane k at [k * TE + entry]): (direction, tmax)
-	M* sm = (M*)(sd + (size_t)TE * NP);
-	unsigned short* sidx = (unsigned short*)(sm + (size_t)TE * NP);
-	unsigned char* vis = (unsigned char*)(sidx + (size_t)TE * NP);
-	for (int i = threadIdx.x; i < 4 * sc.n_prims; i += JP_BLOCK) prims[5 * (i >> 2) + (i & 3)] = sc.prims[i];
-	if (threadIdx.x < JP_SORT_BINS) hist[threadIdx.x] = 0;
-	const unsigned int b = blockIdx.x, E = q.blk_sh[b], rbase = b * q.R;
-	__syncthreads();
-	unsigned int rays = 0, occ = 0;
-	for (unsigned int e0 = 0; e0 < E; e0 += TE)
-	{
-		const unsigned int count = E - e0 < (unsigned int)TE ? E - e0 : (unsigned int)TE;
-		unsigned int kr[kEPT][4];                                    // more than 4 planes never reach this kernel (host check)
-		#pragma unroll
-		for (int r = 0; r < kEPT; r++)
-		{
-			const unsigned int le = r * JP_BLOCK + threadIdx.x;
-			#pragma unroll
-			for (int k = 0; k < 4; k++) kr[r][k] = 0xffffffffu;
-			if (le < count)
-			{
-				const float4 o4 = q.sh_o[rbase + e0 + le];
-				eo[le] = o4;
-				const int nr = (__float_as_int(o4.w) >> 24) & 0xff;
-				#pragma unroll
-				for (int k = 0; k < 4; k++)
-				{
-					if (k < nr)
-					{
-						const float4 d4 = q.sh_d[(size_t)k * q.cap + rbase + e0 + le];
-						const M mask = flat_boxes<k64>(sc.flat, sc.n_flat, xyz(o4), xyz(d4), 0.001f, d4.w);
-						const unsigned int rid = k * TE + le;
-						vis[rid] = mask == 0 ? 1 : 0;                // no box entered: nothing can occlude
-						if (mask != 0)
-						{
-							sd[rid] = d4; sm[rid] = mask;
-							const unsigned int key = min(mask_count<k64>(mask), JP_SORT_BINS - 1);
-							kr[r][k] = (key << 16) | atomicAdd(&hist[key], 1u);
-						}
-					}
-				}
-			}
-		}
-		__syncthreads();
-		sort_scan(hist, base);
-		__syncthreads();
-		#pragma unroll
-		for (int r = 0; r < kEPT; r++)
-		{
-			#pragma unroll
-			for (int k = 0; k < 4; k++)
-				if (kr[r][k] != 0xffffffffu) sidx[base[kr[r][k] >> 16] + (kr[r][k] & 0xffffu)] = (unsigned short)(k * TE + r * JP_BLOCK + threadIdx.x);
-		}
-		__syncthreads();
-		const unsigned int total = base[JP_SORT_BINS];
-		#pragma unroll 1
-		for (unsigned int pos = threadIdx.x; pos < total; pos += JP_BLOCK)
-		{
-			const unsigned int rid = sidx[pos];
-			const float4 o4 = eo[rid & (TE - 1)], d4 = sd[rid];
-			float tmax = d4.w;
-			const int hit = flat_prims<true, k64, 5>(sm[rid], prims, xyz(o4), xyz(d4), 0.001f, tmax);
-			vis[rid] = hit < 0 ? 1 : 0;
-		}
-		__syncthreads();
-		// ---- the entries' sums, in light order ----
-		#pragma unroll
-		for (int r = 0; r < kEPT; r++)
-		{
-			const unsigned int le = r * JP_BLOCK + threadIdx.x;
-			if (le < count)
-			{
-				const int packed = __float_as_int(eo[le].w);
-				const int slot = packed & 0xffffff, nr = (packed >> 24) & 0xff;
-				unsigned int vm = 0;
-				for (int k = 0; k < nr; k++) vm |= (unsigned int)vis[k * TE + le] << k;
-				rays += nr; occ += nr - __popc(vm);
-				if (vm)
-				{
-					const float4 L = q.lacc[slot];
-					V3 a = mk(L.x, L.y, L.z);
-					for (int k = 0; k < nr; k++)
-						if (vm >> k & 1u) { const float4 c4 = q.sh_c[(size_t)k * q.cap + rbase + e0 + le]; a = a + xyz(c4); }
-					q.lacc[slot] = make_float4(a.x, a.y, a.z, 0.f);
-				}
-			}
-		}
-		// the next tile's phase 1 rewrites only this thread's own eo / vis / sd / sm positions; idx / hist / base follow barriers
-	}
-	for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); occ += __shfl_down(occ, off); }
-	if ((threadIdx.x & 63) == 0) { if (rays) atomicAdd(&cnt->shadow, (unsigned long long)rays); if (occ) atomicAdd(&cnt->shadow_occ, (unsigned long long)occ); }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // k_other: the reference's other two integrators behind the same Render() seam, as a megakernel --
 // one thread owns one camera sample and walks it to the end; not the hot path, no queues.
 //   FWhittedIntegrator::Li integrator.cc:115-220 branches: a mirror matches SpecularReflect AND SpecularReflectAndTransmit
@@ -1278,7 +1058,6 @@ struct JpContext
 	bool build_on_device = false; float build_ms = 0.f; int bvh_height = 0, bvh_nodes = 0;
 	bool tables_in_lds = false, stage_nee = false; size_t shade_lds_bytes = 0;
 	int class_mask = 0x3f; bool shade_sort = false;                                     // k_shade partitions its tiles by material class (scenes with more than one material kind)
-	bool flat_sort = false; int flat_rpt = 4, flat_ept = 2; size_t flat_lds_extend = 0, flat_lds_shadow = 0;   // mode 2: tile-sorted traversal kernels (k_extend_flat / k_shadow_flat)
 	// queues
 	Queues q; unsigned int cap = 0; int planes_alloc = 0; unsigned int blk_alloc = 0; int blocks_per_cu = 16;
 	std::vector<void*> qbufs;
@@ -1904,17 +1683,14 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		c->class_mask = 1; for (int k = 0; k < 5; k++) if (kinds[k]) c->class_mask |= 2 << k;
 		if (const char* e = getenv("JETPBRT_SHADE_SORT")) c->shade_sort = atoi(e) != 0;
 	}
-	{   // mode 2: the tile-sorted traversal kernels (k_extend_flat / k_shadow_flat); JETPBRT_FLAT_SORT=0 keeps the unsorted pair
-		c->flat_sort = false;                                       // opt-in while it is being tuned (measured: fewer instructions, no less time yet)
-		if (const char* e = getenv("JETPBRT_FLAT_SORT")) c->flat_sort = atoi(e) != 0 && c->trav_mode == 2 && c->n_planes <= 4;
-		c->flat_rpt = 4; c->flat_ept = c->n_planes <= 2 ? 2 : 1;
-		if (const char* e = getenv("JETPBRT_FLAT_RPT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) c->flat_rpt = v; }
-		if (const char* e = getenv("JETPBRT_FLAT_EPT")) { int v = atoi(e); if (v == 1 || v == 2 || (v == 4 && c->n_planes <= 2)) c->flat_ept = v; }
-		const size_t head = prim_bytes + (32 + 36) * sizeof(unsigned int), mbytes = nmeta > 32 ? 8 : 4;
-		const size_t T = (size_t)c->flat_rpt * JP_BLOCK, TE = (size_t)c->flat_ept * JP_BLOCK;
-		c->flat_lds_extend = head + T * (32 + 2);
-		c->flat_lds_shadow = head + TE * 16 + TE * c->n_planes * (16 + mbytes + 2 + 1);
-		if (c->flat_lds_extend > 64 * 1024 || c->flat_lds_shadow > 64 * 1024) c->flat_sort = false;
+	{   // material sort in k_shade: pays when the primitives carry more than one material kind (JETPBRT_SHADE_SORT = 0 / 1 forces it)
+		bool kinds[8] = { false, false, false, false, false, false, false, false }; int nk = 0;
+		for (int i = 0; i < s->n_primitives; i++) { const int m = s->prim_material[i]; const int k = m < 0 ? 7 : s->mat_type[m]; if (!kinds[k]) { kinds[k] = true; nk++; } }
+		c->ray_sort = false;                                        // opt-in: JETPBRT_RAY_SORT=1 (tiny scenes: by primitive-test count; others: by cut boxes entered)
+		if (const char* e = getenv("JETPBRT_RAY_SORT")) c->ray_sort = atoi(e) != 0 && (c->trav_mode == 2 || ((c->trav_mode == 0 || c->trav_mode == 3) && !cut.empty()));
+		c->shade_sort = nk > 1;
+		c->class_mask = 1; for (int k = 0; k < 5; k++) if (kinds[k]) c->class_mask |= 2 << k;
+		if (const char* e = getenv("JETPBRT_SHADE_SORT")) c->shade_sort = atoi(e) != 0;
 	}
 	c->has_null_material = hasNull;
 	c->have_scene = true;
@@ -2046,15 +1822,6 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 						if (c->trav_mode == 2) hipLaunchKernelGGL(k_extend_sort<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
 						else hipLaunchKernelGGL(k_extend_sort<0>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
 					}
-					else if (c->flat_sort)
-					{
-						const bool w = c->sv.n_prims > 32;
-						#define JP_LAUNCH_EF(R, W) hipLaunchKernelGGL((k_extend_flat<R, W>), dim3(grid), dim3(JP_BLOCK), c->flat_lds_extend, c->stream, c->sv, c->q, cur, c->d_cnt)
-						if (c->flat_rpt == 4) { if (w) JP_LAUNCH_EF(4, true); else JP_LAUNCH_EF(4, false); }
-						else if (c->flat_rpt == 2) { if (w) JP_LAUNCH_EF(2, true); else JP_LAUNCH_EF(2, false); }
-						else { if (w) JP_LAUNCH_EF(1, true); else JP_LAUNCH_EF(1, false); }
-						#undef JP_LAUNCH_EF
-					}
 					else if (c->trav_mode == 5) hipLaunchKernelGGL(k_extend<5>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
 					else if (c->trav_mode == 2) hipLaunchKernelGGL(k_extend<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
 					else if (c->trav_mode == 1) hipLaunchKernelGGL(k_extend<1>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
@@ -2078,15 +1845,6 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 						if (c->trav_mode == 2) hipLaunchKernelGGL(k_shadow_sort<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 						else if (c->trav_mode == 3) hipLaunchKernelGGL(k_shadow_sort<3>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes_shadow, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 						else hipLaunchKernelGGL(k_shadow_sort<0>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
-					}
-					else if (c->flat_sort)
-					{
-						const bool w = c->sv.n_prims > 32;
-						#define JP_LAUNCH_SF(E, W) hipLaunchKernelGGL((k_shadow_flat<E, W>), dim3(grid), dim3(JP_BLOCK), c->flat_lds_shadow, c->stream, c->sv, c->q, rc, c->d_cnt)
-						if (c->flat_ept == 4) { if (w) JP_LAUNCH_SF(4, true); else JP_LAUNCH_SF(4, false); }
-						else if (c->flat_ept == 2) { if (w) JP_LAUNCH_SF(2, true); else JP_LAUNCH_SF(2, false); }
-						else { if (w) JP_LAUNCH_SF(1, true); else JP_LAUNCH_SF(1, false); }
-						#undef JP_LAUNCH_SF
 					}
 					else if (c->trav_mode == 3) hipLaunchKernelGGL(k_shadow<3>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes_shadow, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 					else if (c->trav_mode == 5) hipLaunchKernelGGL(k_shadow<5>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
@@ -2138,7 +1896,7 @@ void sync_lane_scene(JpContext* c, JpContext* l)
 {
 	l->have_scene = c->have_scene; l->sv = c->sv; l->stack_depth = c->stack_depth; l->scene_in_lds = c->scene_in_lds;
 	l->lds_bytes = c->lds_bytes; l->lds_bytes_shadow = c->lds_bytes_shadow; l->trav_mode = c->trav_mode; l->n_planes = c->n_planes;
-	l->ray_sort = c->ray_sort; l->shade_sort = c->shade_sort; l->class_mask = c->class_mask; l->flat_sort = c->flat_sort; l->flat_rpt = c->flat_rpt; l->flat_ept = c->flat_ept; l->flat_lds_extend = c->flat_lds_extend; l->flat_lds_shadow = c->flat_lds_shadow;
+	l->ray_sort = c->ray_sort; l->shade_sort = c->shade_sort; l->class_mask = c->class_mask;
 	l->has_null_material = c->has_null_material; l->tables_in_lds = c->tables_in_lds; l->stage_nee = c->stage_nee; l->shade_lds_bytes = c->shade_lds_bytes;
 	l->profiling = c->profiling;
 }

@@ -12,14 +12,14 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + names, stdout=subprocess.PIPE, text=True).stdout.split("\n")
+        out = subprocess.run(["c++filt"] + names, stdout=subprocess.PIPE, text=True).stdout.split("\n")
         return [o if o else n for o, n in zip(out, names)]
     except Exception:
         return names
 
 
 def short(n):
-    n = re.sub(r"\(.*", "", n)                       # drop the argument list
+    n = re.sub(r"\(jp::SceneView.*|\((?:unsigned|int|float|HIP|Queues|JpBsdf|Wide).*", "", n)   # drop the argument list, keep template arguments
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     return n
 
