@@ -421,4 +421,137 @@ __device__ __forceinline__ int traverse_wide(const uint4* __restrict__ wide, Pri
 	return hit;
 }
 
+// ---- resumable traversal ("walkers") for the lane-refill kernels (k_extend_persist / k_shadow_persist, jp_kernels.hip) -------------
+// The same three traversals as above -- traverse (mode 0), traverse_wide (mode 3), traverse_ref (mode 5) -- cut into steps: one
+// step() handles ONE interior node, ONE leaf (mode 0 / 5) or one primitive / one pop (mode 3), so that the lanes of a wave, each at
+// its own stage of its own ray, advance together and a finished lane can take the next ray while the others go on.  The order in
+// which a ray's nodes and primitives are visited, the arithmetic and the acceptance rules are those of the loops above: identical
+// hit records.  `stack` is the thread's column of the LDS stack.  done: the ray is finished (hit >= 0: accepted primitive).
+template <int kMode> struct Walker;
+
+template <> struct Walker<0>
+{
+	V3 o, d; float ix, iy, iz, tmin, tmax; int cur, sp, hit; bool done;
+	__device__ __forceinline__ void start(V3 o_, V3 d_, float tmin_, float tmax_)
+	{ o = o_; d = d_; ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z; tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; done = false; }
+	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, int* stack)
+	{
+		if (cur >= 0)
+		{
+			const float4* __restrict__ nodes = sc.nodes;
+			const float4 n0 = nodes[4 * cur + 0], n1 = nodes[4 * cur + 1], n2 = nodes[4 * cur + 2], n3 = nodes[4 * cur + 3];
+			const float lx0 = (n0.x - o.x) * ix, lx1 = (n0.w - o.x) * ix;
+			const float ly0 = (n0.y - o.y) * iy, ly1 = (n1.x - o.y) * iy;
+			const float lz0 = (n0.z - o.z) * iz, lz1 = (n1.y - o.z) * iz;
+			const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), tmin));
+			const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), tmax));
+			const float rx0 = (n1.z - o.x) * ix, rx1 = (n2.y - o.x) * ix;
+			const float ry0 = (n1.w - o.y) * iy, ry1 = (n2.z - o.y) * iy;
+			const float rz0 = (n2.x - o.z) * iz, rz1 = (n2.w - o.z) * iz;
+			const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), tmin));
+			const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), tmax));
+			const bool hl = ln <= lf * 1.000002f, hr = rn <= rf * 1.000002f;
+			const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
+			if (hl && hr)
+			{
+				const bool leftFirst = kAnyHit ? true : (ln <= rn);
+				cur = leftFirst ? cl : cr;
+				stack[sp * JP_BLOCK] = leftFirst ? cr : cl; sp++;
+			}
+			else if (hl) cur = cl;
+			else if (hr) cur = cr;
+			else if (sp > 0) { sp--; cur = stack[sp * JP_BLOCK]; }
+			else done = true;
+		}
+		else
+		{
+			const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
+			for (int k = 0; k < count; k++)
+				if (prim_hit<4>(sc.prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) { done = true; return; } }
+			if (sp > 0) { sp--; cur = stack[sp * JP_BLOCK]; } else done = true;
+		}
+	}
+};
+
+template <> struct Walker<5>
+{
+	V3 o, d, rd; float tmin, tmax; int cur, sp, hit; bool done;
+	__device__ __forceinline__ void start(V3 o_, V3 d_, float tmin_, float tmax_)
+	{ o = o_; d = d_; rd = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; done = false; }
+	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, int* stack)
+	{   // traverse_ref: the node's own box, then left, then right; every object of a leaf in order
+		const float4* __restrict__ nodes = sc.nodes;
+		const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+		const bool ok = ref_box(n0, n1, o, d, rd, tmin, tmax);
+		const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+		if (ok && left >= 0) { stack[sp * JP_BLOCK] = right; sp++; cur = left; return; }
+		if (ok)
+		{
+			const int first = -left - 1;
+			for (int k = 0; k < right; k++)
+				if (prim_hit<4>(sc.prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) { done = true; return; } }
+		}
+		if (sp == 0) { done = true; return; }
+		sp--; cur = stack[sp * JP_BLOCK];
+	}
+};
+
+template <> struct Walker<3>
+{
+	V3 o, d; float ix, iy, iz, tmin, tmax; unsigned int ngx, ngy, tgx, tgy, octinv; int sp, hit; bool done;
+	__device__ __forceinline__ void start(V3 o_, V3 d_, float tmin_, float tmax_)
+	{
+		o = o_; d = d_; ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z; tmin = tmin_; tmax = tmax_;
+		octinv = 7u - ((d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u));
+		ngx = 0; ngy = 0x80000000u; tgx = tgy = 0; sp = 0; hit = -1; done = false;       // the root: group base 0, one pending inner hit
+	}
+	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, int* stack_)
+	{
+		unsigned int* stack = (unsigned int*)stack_;
+		if (tgy)
+		{   // one primitive
+			const int j = __ffs((int)tgy) - 1;
+			tgy &= tgy - 1;
+			if (prim_hit<4>(sc.prims, (int)tgx + j, o, d, tmin, tmax)) { hit = (int)tgx + j; if (kAnyHit) done = true; }
+		}
+		else if (ngy > 0x00ffffffu)
+		{   // one wide node (traverse_wide)
+			const uint4* __restrict__ wide = sc.wide;
+			const unsigned int bit = 31u - (unsigned int)__clz((int)ngy);
+			ngy &= ~(1u << bit);
+			if (ngy > 0x00ffffffu) { stack[(2 * sp) * JP_BLOCK] = ngx; stack[(2 * sp + 1) * JP_BLOCK] = ngy; sp++; }
+			const unsigned int slot = (bit - 24u) ^ octinv;
+			const unsigned int rel = (unsigned int)__popc(ngy & 0xffu & ~(0xffffffffu << slot));
+			const unsigned int idx = ngx + rel;
+			const uint4 q0 = wide[5 * idx + 0], q1 = wide[5 * idx + 1], q2 = wide[5 * idx + 2], q3 = wide[5 * idx + 3], q4 = wide[5 * idx + 4];
+			const float sx = __uint_as_float(((q0.w & 0xffu) ) << 23), sy = __uint_as_float(((q0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
+			const float px = __uint_as_float(q0.x) - o.x, py = __uint_as_float(q0.y) - o.y, pz = __uint_as_float(q0.z) - o.z;
+			unsigned int hm = 0;
+			#pragma unroll
+			for (int i = 0; i < 8; i++)
+			{
+				const int sh = 8 * (i & 3);
+				const unsigned int m = ((i < 4 ? q1.z : q1.w) >> sh) & 0xffu;
+				const float lx = (float)(((i < 4 ? q2.x : q2.y) >> sh) & 0xffu), ly = (float)(((i < 4 ? q2.z : q2.w) >> sh) & 0xffu), lz = (float)(((i < 4 ? q3.x : q3.y) >> sh) & 0xffu);
+				const float hx = (float)(((i < 4 ? q3.z : q3.w) >> sh) & 0xffu), hy = (float)(((i < 4 ? q4.x : q4.y) >> sh) & 0xffu), hz = (float)(((i < 4 ? q4.z : q4.w) >> sh) & 0xffu);
+				const float x0 = fmaf(lx, sx, px) * ix, x1 = fmaf(hx, sx, px) * ix;
+				const float y0 = fmaf(ly, sy, py) * iy, y1 = fmaf(hy, sy, py) * iy;
+				const float z0 = fmaf(lz, sz, pz) * iz, z1 = fmaf(hz, sz, pz) * iz;
+				const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+				const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+				if (m != 0u && tn <= tf * 1.000002f)
+				{
+					const bool inner = (m & 0x18u) == 0x18u;
+					const unsigned int bits = inner ? 1u : (m >> 5), at = inner ? 24u + ((m & 7u) ^ octinv) : (m & 31u);
+					hm |= bits << at;
+				}
+			}
+			ngx = q1.x; ngy = (hm & 0xff000000u) | (q0.w >> 24);
+			tgx = q1.y; tgy = hm & 0x00ffffffu;
+		}
+		else if (sp > 0) { sp--; ngx = stack[(2 * sp) * JP_BLOCK]; ngy = stack[(2 * sp + 1) * JP_BLOCK]; }
+		else done = true;
+	}
+};
+
 } // namespace jp
