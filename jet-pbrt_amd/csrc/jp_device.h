@@ -434,6 +434,7 @@ template <> struct Walker<0>
 	V3 o, d; float ix, iy, iz, tmin, tmax; int cur, sp, hit; bool done;
 	__device__ __forceinline__ void start(V3 o_, V3 d_, float tmin_, float tmax_)
 	{ o = o_; d = d_; ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z; tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; done = false; }
+	__device__ __forceinline__ bool heavy() const { return cur < 0; }                 // next step is a leaf (primitive tests), not a node
 	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, int* stack)
 	{
 		if (cur >= 0)
@@ -464,7 +465,7 @@ template <> struct Walker<0>
 			else done = true;
 		}
 		else
-		{
+		{   // one leaf per step (measured: one primitive per step is better without the vote, 28.3 -> 23.9 ms, worse with it, 21.9 -> 23.2)
 			const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
 			for (int k = 0; k < count; k++)
 				if (prim_hit<4>(sc.prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) { done = true; return; } }
@@ -475,21 +476,26 @@ template <> struct Walker<0>
 
 template <> struct Walker<5>
 {
-	V3 o, d, rd; float tmin, tmax; int cur, sp, hit; bool done;
+	V3 o, d, rd; float tmin, tmax; int cur, sp, hit, lfirst, lcount, lk; bool done;
 	__device__ __forceinline__ void start(V3 o_, V3 d_, float tmin_, float tmax_)
-	{ o = o_; d = d_; rd = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; done = false; }
+	{ o = o_; d = d_; rd = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; lcount = 0; lk = 0; lfirst = 0; done = false; }
+	__device__ __forceinline__ bool heavy() const { return lcount > 0; }             // next step tests an object of the leaf just entered
 	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, int* stack)
 	{   // traverse_ref: the node's own box, then left, then right; every object of a leaf in order
-		const float4* __restrict__ nodes = sc.nodes;
-		const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
-		const bool ok = ref_box(n0, n1, o, d, rd, tmin, tmax);
-		const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-		if (ok && left >= 0) { stack[sp * JP_BLOCK] = right; sp++; cur = left; return; }
-		if (ok)
+		if (lcount > 0)
 		{
-			const int first = -left - 1;
-			for (int k = 0; k < right; k++)
-				if (prim_hit<4>(sc.prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) { done = true; return; } }
+			if (prim_hit<4>(sc.prims, lfirst + lk, o, d, tmin, tmax)) { hit = lfirst + lk; if (kAnyHit) { done = true; return; } }
+			if (++lk < lcount) return;
+			lcount = 0; lk = 0;
+		}
+		else
+		{
+			const float4* __restrict__ nodes = sc.nodes;
+			const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+			const bool ok = ref_box(n0, n1, o, d, rd, tmin, tmax);
+			const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+			if (ok && left >= 0) { stack[sp * JP_BLOCK] = right; sp++; cur = left; return; }
+			if (ok && right > 0) { lfirst = -left - 1; lcount = right; lk = 0; return; }
 		}
 		if (sp == 0) { done = true; return; }
 		sp--; cur = stack[sp * JP_BLOCK];
@@ -505,6 +511,7 @@ template <> struct Walker<3>
 		octinv = 7u - ((d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u));
 		ngx = 0; ngy = 0x80000000u; tgx = tgy = 0; sp = 0; hit = -1; done = false;       // the root: group base 0, one pending inner hit
 	}
+	__device__ __forceinline__ bool heavy() const { return tgy == 0u && ngy > 0x00ffffffu; }   // next step decodes a wide node (8 boxes), not a primitive / pop
 	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, int* stack_)
 	{
 		unsigned int* stack = (unsigned int*)stack_;

@@ -28,6 +28,9 @@ os.makedirs(dst, exist_ok=True)
 
 def cls_of(kernel):
     k = kernel.replace("void ", "").split("<")[0].split("(")[0]
+    for base in ("k_extend", "k_shadow", "k_shade"):            # k_extend_sort / k_extend_persist ... count as their class
+        if k.startswith(base + "_") or k == base:
+            return base
     return k
 
 
