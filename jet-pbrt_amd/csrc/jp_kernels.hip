@@ -1964,11 +1964,6 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 					{
 						#define JP_LAUNCH_EP(M, R) do { if (c->vote) hipLaunchKernelGGL((k_extend_persist<M, R, true>), dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->d_cnt); else hipLaunchKernelGGL((k_extend_persist<M, R, false>), dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->d_cnt); } while (0)
 						if (c->trav_mode == 5) { if (c->persist >= 32) JP_LAUNCH_EP(5, 32); else if (c->persist >= 16) JP_LAUNCH_EP(5, 16); else JP_LAUNCH_EP(5, 8); }
-						else if (c->trav_mode == 3 && getenv("JETPBRT_EXTEND_WIDE"))
-						{   // experiment: closest hits through the 8-wide tree as well (approximate child order)
-							if (c->vote) hipLaunchKernelGGL((k_extend_persist<3, 16, true>), dim3(grid), dim3(JP_BLOCK), c->lds_bytes_shadow, c->stream, c->sv, c->q, cur, c->d_cnt);
-							else hipLaunchKernelGGL((k_extend_persist<3, 16, false>), dim3(grid), dim3(JP_BLOCK), c->lds_bytes_shadow, c->stream, c->sv, c->q, cur, c->d_cnt);
-						}
 						else { if (c->persist >= 32) JP_LAUNCH_EP(0, 32); else if (c->persist >= 16) JP_LAUNCH_EP(0, 16); else JP_LAUNCH_EP(0, 8); }
 						#undef JP_LAUNCH_EP
 					}

@@ -955,3 +955,49 @@ def test_host_reflection_classes_and_other_samplers(H, gpu_ctx):
     assert_film(gpu_ctx, films[2], ref, "cornell")
     one, _ = H.oracle_render(sp, H.jp.render_params(W, Hh, 1, 5, 0, H.jp.JP_SAMPLER_DEBUG), 4)
     assert l2(one, ref) < 1e-6                                    # constant draws: every sample of a pixel is the same path
+
+
+@pytest.mark.parametrize("name", ["misc", "bunny_small", "lights"])
+def test_wavefront_sorts_and_lane_refill_do_not_change_the_film(H, gpu_ctx, monkeypatch, name):
+    """the round-2 scheduling changes only move work between lanes: material sort in k_shade on / off, ray sort in the traversal
+    kernels, lane refill (k_extend_persist / k_shadow_persist) with every refill threshold and with / without the vote, on the binary
+    tree (mode 0, forced), the 8-wide shadow tree and the reference tree, a scene with a null-material primitive (extra iterations),
+    tiny regions (one workgroup per 256 slots) and a region count that leaves most lanes without a ray -- all bit-identical"""
+    W, Hh, spp = 96, 64, 6
+    hb, sp = _scene(H, name, W, Hh)
+    p = H.jp.render_params(W, Hh, spp, 5, 77)
+
+    def render(env, scene_ptr=sp):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = H.jp.Context(0)
+        try:
+            ctx.upload(scene_ptr)
+            film = ctx.render(p); c = ctx.counters(); mode = ctx.build_info().traversal_mode
+        finally:
+            ctx.close()
+            for k in env:
+                monkeypatch.delenv(k)
+        return film, (c.closest_rays, c.closest_hits, c.shadow_rays, c.shadow_occluded), mode
+
+    base, cnt, mode = render({"JETPBRT_SHADE_SORT": "0", "JETPBRT_PERSIST": "0"})
+    variants = [{"JETPBRT_SHADE_SORT": "1", "JETPBRT_PERSIST": "0"}, {"JETPBRT_RAY_SORT": "1", "JETPBRT_PERSIST": "0"}]
+    if mode != 2:                                                  # walked through global memory: the refill kernels apply
+        variants += [{"JETPBRT_PERSIST": r, "JETPBRT_VOTE": v} for r in ("8", "16", "32") for v in ("0", "1")]
+        variants += [{"JETPBRT_PERSIST": "16", "JETPBRT_BLOCKS_PER_CU": "64"}, {"JETPBRT_PERSIST": "16", "JETPBRT_MAX_SLOTS": str(W * Hh)}]
+    for env in variants:
+        film, c2, _ = render(env)
+        assert np.array_equal(film.view(np.uint32), base.view(np.uint32)) and c2 == cnt, env
+    # the binary tree in global memory (mode 0), forced, with and without refill
+    f0, c0, m0 = render({"JETPBRT_TRAVERSAL": "0", "JETPBRT_PERSIST": "0"})
+    f1, c1, m1 = render({"JETPBRT_TRAVERSAL": "0", "JETPBRT_PERSIST": "16"})
+    assert m0 == m1 and np.array_equal(f0.view(np.uint32), f1.view(np.uint32)) and c0 == c1
+    assert m0 == 0 and l2(f1, base) < TOL_L2                      # another tree than the default's: the gate (fringe hits on the mesh scene)
+    if name != "bunny_small":
+        assert (f1 == base).all(-1).mean() >= 0.999 and l2(f1, base) < 1e-6
+    # the reference tree with refill on (forced on this small scene) and off
+    rb, rsp = _reference_tree_scene(H, name, W, Hh)
+    r0, rc0, rm = render({"JETPBRT_PERSIST": "0"}, rsp)
+    for r, v in (("8", "0"), ("16", "0"), ("16", "1"), ("32", "0")):
+        r1, rc1, _ = render({"JETPBRT_PERSIST": r, "JETPBRT_VOTE": v}, rsp)
+        assert rm == 5 and np.array_equal(r0.view(np.uint32), r1.view(np.uint32)) and rc0 == rc1, (r, v)
