@@ -11,6 +11,10 @@
 //              surviving paths compacted (wave ballots + block prefix) into the next ray queue
 //   k_shadow   any-hit traversal per shadow entry, visible contributions added to the path's radiance in light order
 //   k_resolve  per pixel: sequential fp32 sum over the batch's samples in index order (integrator.cc:102-105)
+// Round 2: k_shade partitions its 1024-path tiles by material class first (tile_partition: wave ballots + block prefix);
+// large scenes trace through k_extend_persist / k_shadow_persist (resumable Walker<mode> steps, idle lanes refilled from the
+// region, per-iteration vote); k_extend_sort / k_shadow_sort (opt-in) partition rays by expected work; k_tonemap8 delivers the
+// film as 8-bit gamma-encoded RGB; k_bsdf evaluates any BSDF class of bsdf.h by value (jp_xbsdf.h).
 // Queues are SoA float4 arrays in HBM cut into one REGION per workgroup: block b reads region b of the input queue
 // and appends to region b of the output queues with a running offset, so compaction needs no global atomic and the
 // layout is deterministic.  Launches are asynchronous on one stream, no host round trip inside a batch.
