@@ -265,3 +265,27 @@ def test_film_writers_equal_the_reference_writers_byte_for_byte(H, tmp_path):
         yr = np.zeros(xr.size, np.uint8)
         H.ref_lib().ref_gamma_encode(H.ptr(xr), xr.size, H.ptr(yr))
         assert np.array_equal(np.searchsorted(thr, xr, side="right").astype(np.uint8), yr)
+
+
+def test_kernel_register_budgets(H, tmp_path):
+    """Occupancy cliffs, checked at build time (no GPU): hipcc's resource-usage remarks for the kernels of the benchmark configurations.
+    k_shade sits at 167 VGPRs with the material sort -- 168 is the last count that still fits 3 waves per SIMD (512 / 168), and a build
+    that crossed it lost 25 % on configs[2] during round 2; the traversal kernels must keep 8 waves per SIMD (<= 64 VGPRs), the refill
+    kernels too.  No kernel may spill."""
+    import subprocess
+    csrc = os.path.join(H.REPO, "jet-pbrt_amd", "csrc")
+    subprocess.run(["make", "-s", "asm"], cwd=csrc, check=True)
+    out = subprocess.run(["python", os.path.join(H.REPO, "tools", "resource_table.py")], stdout=subprocess.PIPE, text=True, check=True).stdout
+    rows = {}
+    for line in out.splitlines()[1:]:
+        m = re.match(r"(.+?)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)$", line)
+        if m:
+            rows[m.group(1).strip()] = dict(vgpr=int(m.group(2)), scratch=int(m.group(5)), waves=int(m.group(6)))
+    assert len(rows) > 40
+    for name in ("k_shade<true, true, true, true>", "k_shade<true, true, true, false>", "k_shade<true, false, true, true>"):
+        assert rows[name]["vgpr"] <= 168 and rows[name]["waves"] >= 3 and rows[name]["scratch"] == 0, (name, rows[name])
+    for name in ("k_extend<2>", "k_extend<0>", "k_extend_persist<0, 16, true>", "k_shadow_persist<3, 16, true>", "k_extend_persist<5, 16, false>"):
+        assert rows[name]["vgpr"] <= 64 and rows[name]["waves"] == 8 and rows[name]["scratch"] == 0, (name, rows[name])
+    assert rows["k_shadow<2>"]["waves"] >= 6
+    spills = [n for n, r in rows.items() if r["scratch"] and not n.startswith(("k_other", "k_wide_level"))]
+    assert not spills, spills
