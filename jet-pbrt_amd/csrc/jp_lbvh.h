@@ -9,7 +9,7 @@
 // Pipeline (all on the context stream, no host round trip until the final height read-back):
 //   k_lbvh_bounds   exact extent of every primitive + scene extent (wave-reduced, ordered-uint atomics)
 //   k_lbvh_morton   63-bit Morton code of the box centre (21 bits per axis)
-//   hipcub radix sort (key = code, value = primitive)
+//   lbvh_sort       own LSD radix sort of (code, primitive) pairs, 8 bits per pass, stable (k_rs_hist / k_rs_scan / k_rs_scatter)
 //   k_lbvh_gather   primitive records / meta / boxes into sorted order (= device primitive order)
 //   k_lbvh_hier     Karras 2012: one thread per interior node finds its range and split (duplicate codes are
 //                   disambiguated by index, so the tree is a function of the sorted order alone)
@@ -19,7 +19,6 @@
 //   k_lbvh_depth    height of the emitted tree (sizes the per-lane LDS traversal stack)
 #ifndef JP_LBVH_H
 #define JP_LBVH_H
-#include <hipcub/hipcub.hpp>
 
 __device__ __forceinline__ unsigned int lbvh_ord(float f) { const unsigned int b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float lbvh_unord(unsigned int u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
@@ -231,6 +230,102 @@ __global__ void k_lbvh_single(const float4* __restrict__ lo, const float4* __res
 
 struct LbvhResult { void* d_nodes = nullptr; void* d_prims = nullptr; void* d_meta = nullptr; int n_nodes = 0, height = 0; float build_ms = 0.f; };
 
+// ---- LSD radix sort of (64-bit code, primitive index) pairs: 8 passes of 8 bits, stable --------------------------------------
+// (round 1 called hipcub here; the sort is off the hot path -- 280k pairs once per scene upload -- but it is the step that
+// decides the primitive order on the device, so it is own code like the rest.)  Per pass: k_rs_hist counts the digit values
+// of every 2048-pair tile (LDS atomics), k_rs_scan turns the digit-major table of counts into global offsets, k_rs_scatter
+// moves each tile's pairs, 256 at a time, to offset[digit][tile] + rank, the rank taken in tile order (wave match by eight
+// ballots + per-wave counts through LDS), which keeps equal codes in index order: coincident primitives sort deterministically.
+#define JP_RS_ITEMS 8
+__global__ void __launch_bounds__(256) k_rs_hist(const unsigned long long* __restrict__ keys, int n, int shift, unsigned int* __restrict__ table, int ntiles)
+{
+	__shared__ unsigned int h[256];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	const int base = blockIdx.x * 256 * JP_RS_ITEMS;
+	for (int r = 0; r < JP_RS_ITEMS; r++)
+	{
+		const int i = base + r * 256 + threadIdx.x;
+		if (i < n) atomicAdd(&h[(unsigned int)(keys[i] >> shift) & 255u], 1u);
+	}
+	__syncthreads();
+	table[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];       // digit-major: the exclusive scan gives [digit][tile] offsets
+}
+__global__ void __launch_bounds__(256) k_rs_scan(unsigned int* table, int total)
+{   // one workgroup: exclusive scan of `total` counters in chunks of 256 with a running carry
+	__shared__ unsigned int s[256];
+	__shared__ unsigned int carry;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (int base = 0; base < total; base += 256)
+	{
+		const int i = base + threadIdx.x;
+		const unsigned int v = i < total ? table[i] : 0u;
+		s[threadIdx.x] = v;
+		__syncthreads();
+		for (int off = 1; off < 256; off <<= 1)
+		{
+			const unsigned int t = threadIdx.x >= (unsigned int)off ? s[threadIdx.x - off] : 0u;
+			__syncthreads();
+			s[threadIdx.x] += t;
+			__syncthreads();
+		}
+		if (i < total) table[i] = carry + s[threadIdx.x] - v;
+		__syncthreads();
+		if (threadIdx.x == 255) carry += s[255];
+		__syncthreads();
+	}
+}
+__global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __restrict__ keys, const int* __restrict__ vals, int n, int shift,
+                                                    const unsigned int* __restrict__ table, int ntiles, unsigned long long* __restrict__ keys_out, int* __restrict__ vals_out)
+{
+	__shared__ unsigned int s_base[256];                             // next free output position of each digit value for this tile
+	__shared__ unsigned int s_cnt[4][256];                           // per wave: pairs of each digit value in the current round
+	s_base[threadIdx.x] = table[threadIdx.x * ntiles + blockIdx.x];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	const int base = blockIdx.x * 256 * JP_RS_ITEMS;
+	for (int r = 0; r < JP_RS_ITEMS; r++)
+	{
+		for (int w = 0; w < 4; w++) s_cnt[w][threadIdx.x] = 0;
+		__syncthreads();
+		const int i = base + r * 256 + threadIdx.x;
+		const bool valid = i < n;
+		unsigned long long key = 0; int val = 0; unsigned int digit = 0;
+		if (valid) { key = keys[i]; val = vals[i]; digit = (unsigned int)(key >> shift) & 255u; }
+		unsigned long long m = __ballot(valid);                      // lanes of this wave with the same digit value
+		for (int bit = 0; bit < 8; bit++) { const unsigned long long bm = __ballot(valid && ((digit >> bit) & 1u)); m &= ((digit >> bit) & 1u) ? bm : ~bm; }
+		const unsigned int rank = (unsigned int)__popcll(m & lt);
+		if (valid && rank == 0) s_cnt[wave][digit] = (unsigned int)__popcll(m);
+		__syncthreads();
+		if (valid)
+		{
+			unsigned int pos = s_base[digit] + rank;
+			for (int w = 0; w < wave; w++) pos += s_cnt[w][digit];
+			keys_out[pos] = key; vals_out[pos] = val;
+		}
+		__syncthreads();
+		s_base[threadIdx.x] += s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+		__syncthreads();
+	}
+}
+// sorts (keys, vals) by key, bits [0, 64); the result is in (keys2, vals2); `table` holds 256 * ntiles counters
+static void lbvh_sort(hipStream_t stream, unsigned long long* keys, unsigned long long* keys2, int* vals, int* vals2, int n, unsigned int* table)
+{
+	const int ntiles = (n + 256 * JP_RS_ITEMS - 1) / (256 * JP_RS_ITEMS);
+	unsigned long long *ka = keys, *kb = keys2; int *va = vals, *vb = vals2;
+	for (int pass = 0; pass < 8; pass++)
+	{
+		hipLaunchKernelGGL(k_rs_hist, dim3(ntiles), dim3(256), 0, stream, (const unsigned long long*)ka, n, 8 * pass, table, ntiles);
+		hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(256), 0, stream, table, 256 * ntiles);
+		hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles), dim3(256), 0, stream, (const unsigned long long*)ka, (const int*)va, n, 8 * pass, (const unsigned int*)table, ntiles, kb, vb);
+		std::swap(ka, kb); std::swap(va, vb);
+	}
+	// eight passes: the result is back in (keys, vals); the callers read (keys2, vals2)
+	hipMemcpyAsync(keys2, keys, (size_t)n * 8, hipMemcpyDeviceToDevice, stream);
+	hipMemcpyAsync(vals2, vals, (size_t)n * 4, hipMemcpyDeviceToDevice, stream);
+}
+
 // prims0 / meta0: device arrays in creation order (4 x float4 and one int4 per primitive).  On success the caller
 // owns r.d_nodes / d_prims / d_meta and `order` holds, for each device (sorted) position, the creation-order index.
 static hipError_t lbvh_build(hipStream_t stream, const float4* prims0, const int4* meta0, int n, int maxLeaf, LbvhResult& r, std::vector<int>& order)
@@ -250,7 +345,7 @@ static hipError_t lbvh_build(hipStream_t stream, const float4* prims0, const int
 	    || !dalloc((void**)&scene6, 32, false) || !dalloc((void**)&height, 16, false) || !dalloc((void**)&flag, NI * 4, false)
 	    || !dalloc(&r.d_nodes, NI * 64, true) || !dalloc(&r.d_prims, N * 64, true) || !dalloc(&r.d_meta, N * 16, true))
 		return bail();
-	if ((e = hipcub::DeviceRadixSort::SortPairs(nullptr, sortbytes, keys, keys2, vals, vals2, n, 0, 63, stream)) != hipSuccess) return bail();
+	sortbytes = (size_t)256 * ((N + 256 * JP_RS_ITEMS - 1) / (256 * JP_RS_ITEMS)) * sizeof(unsigned int);
 	if (!dalloc(&sorttmp, sortbytes, false)) return bail();
 	hipEvent_t e0, e1;
 	if ((e = hipEventCreate(&e0)) != hipSuccess) return bail();
@@ -270,7 +365,7 @@ static hipError_t lbvh_build(hipStream_t stream, const float4* prims0, const int
 	else
 	{
 		hipLaunchKernelGGL(k_lbvh_morton, dim3(grid), dim3(256), 0, stream, (const float4*)lo0, (const float4*)hi0, n, (const unsigned int*)scene6, keys, vals);
-		if ((e = hipcub::DeviceRadixSort::SortPairs(sorttmp, sortbytes, keys, keys2, vals, vals2, n, 0, 63, stream)) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return bail(); }
+		lbvh_sort(stream, keys, keys2, vals, vals2, n, (unsigned int*)sorttmp);
 		hipLaunchKernelGGL(k_lbvh_gather, dim3(grid), dim3(256), 0, stream, (const int*)vals2, n, prims0, meta0, (const float4*)lo0, (const float4*)hi0, (float4*)r.d_prims, (int4*)r.d_meta, lo, hi);
 		hipLaunchKernelGGL(k_lbvh_hier, dim3(grid), dim3(256), 0, stream, (const unsigned long long*)keys2, n, childL, childR, parentI, parentL, first, last);
 		hipLaunchKernelGGL(k_lbvh_refit, dim3(grid), dim3(256), 0, stream, n, maxLeaf, (const int*)childL, (const int*)childR, (const int*)parentI, (const int*)parentL,
