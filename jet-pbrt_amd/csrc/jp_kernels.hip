@@ -2092,7 +2092,10 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 			// worth it only when each lane still gets full-size batches (2^24 slots): measured -7 % at 512 x 512 x 64 spp
 			// (half-size batches), +17 % / +24 % at 1024 spp with two / three lanes
 			const long long samples = rows * rp->width * (long long)rp->spp;
-			if (groups >= 48 && samples >= (3ll << 24)) L = 3;
+			// round 2, measured on one rank's share of an 8- / 4-GPU frame (64 / 128 rows of 512 x 512, tools/gpu_shard_lanes.py): three lanes
+			// beat two there as well (1/8 shard at 1024 spp 13.5 vs 14.8 ms, at 8192 spp 2570 vs 2334 Msamples/s), so the lane count follows
+			// the sample count alone
+			if (groups >= 3 && samples >= (2ll << 24)) L = 3;
 			else if (groups >= 2 && samples >= (2ll << 24)) L = 2;
 		}
 	}
