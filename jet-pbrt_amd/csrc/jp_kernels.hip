@@ -1919,6 +1919,11 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 		if (const char* e = getenv("JETPBRT_MAX_SLOTS")) { long long v = atoll(e); if (v > 0) budget = std::min<size_t>(budget, (size_t)v * per); }
 		unsigned int pcap = (unsigned int)std::min<size_t>(PMAX, std::max<size_t>((size_t)npix, budget / per));
 		int sbatch = (int)std::max<long long>(1, std::min<long long>(rp->spp, pcap / npix));
+		{   // equal batches: ceil(spp / sbatch) batches of (nearly) the same size instead of full ones and a remainder (1024 spp in batches of
+			// 192 would end with a 64-spp batch whose launches fill a third of the GPU)
+			const int nb = (rp->spp + sbatch - 1) / sbatch;
+			sbatch = (rp->spp + nb - 1) / nb;
+		}
 		if ((long long)sbatch * npix > (long long)PMAX) return fail(JP_ERR_UNSUPPORTED, "jp_render: shard too large for one batch");
 		const unsigned int P = (unsigned int)((long long)sbatch * npix);
 		const unsigned int nchunks = (P + JP_BLOCK - 1) / JP_BLOCK;
