@@ -131,6 +131,14 @@ __device__ __forceinline__ void block_prefix2(bool fa, bool fb, unsigned int* s_
 	pb = (base >> 16) + (unsigned int)__popcll(mb & lt); tb = tot >> 16;
 }
 
+// wave-level take from an LDS counter: lane 0 adds the wave-uniform n, every lane gets the old value.  All 64 lanes must be active.
+__device__ __forceinline__ unsigned int wave_take(unsigned int* ctr, unsigned int n)
+{
+	unsigned int v = 0;
+	if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, n);
+	return (unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Wavefront-level sort: block-wide STABLE partition of a tile of kRPT x 256 queue entries by a small class key, with wave
 // ballots + popcount prefixes and one block prefix over LDS counters (no atomics: the order is deterministic).
@@ -332,18 +340,20 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend(SceneView sc, Queues q, int
 template <bool kTab, bool kPrims, bool kStage, bool kSort>
 __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, RenderConst rc, int cur, DevCounters* cnt)
 {
-	__shared__ unsigned int s_tmp[JP_BLOCK / 64];
-	__shared__ unsigned int s_tmp2[2 * (JP_BLOCK / 64)];
 	constexpr int kRPT = JP_SHADE_TILE / JP_BLOCK, kSeg = kRPT * (JP_BLOCK / 64);       // (pass, wave) segments of a tile, in queue order
 	__shared__ unsigned short s_idx[kSort ? JP_SHADE_TILE : 1];
 	__shared__ unsigned int s_cnt[kSort ? JP_SHADE_CLASSES * kSeg : 1];
-	unsigned int chunk = 0;
+	__shared__ unsigned int s_ctr[3];      // [0] next 64-path chunk of the tile; [1], [2] fill of this block's ray / shadow output regions
+	const unsigned int lane = threadIdx.x & 63u;
 	float4* s_lights = s_dyn;
 	float4* s_mats = s_lights + 2 * sc.n_lights;
 	float4* s_prims = s_mats + 4 * sc.n_mats;
 	int4* s_meta = (int4*)(s_prims + 4 * sc.n_prims);
 	int* s_mtype = kPrims ? (int*)(s_meta + sc.n_prims) : (int*)s_prims;
-	float4* s_stage = (float4*)(((uintptr_t)(s_mtype + sc.n_mats) + 15) & ~(uintptr_t)15) + threadIdx.x;   // [(2k, 2k+1) * 256 + tid]
+	// [(2k, 2k+1) * 256 + tid], behind the tables (an index into s_dyn, not a cast through an integer: the pointer keeps its LDS
+	// address space, so the staging is ds_write / ds_read -- as flat accesses its reads sat behind `s_waitcnt vmcnt(0)`, i.e. behind
+	// the acknowledgement of every store issued before them)
+	float4* s_stage = s_dyn + (2 * sc.n_lights + 4 * sc.n_mats + (kPrims ? 5 * sc.n_prims : 0) + (sc.n_mats + 3) / 4) + threadIdx.x;
 	const unsigned int b = blockIdx.x, n = q.blk_q[cur][b];
 	const int nxt = cur ^ 1;
 	if (n == 0) { if (threadIdx.x == 0) { q.blk_q[nxt][b] = 0; q.blk_sh[b] = 0; } return; }
@@ -358,14 +368,14 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 		for (int i = threadIdx.x; i < 4 * sc.n_prims; i += JP_BLOCK) s_prims[i] = sc.prims[i];
 		for (int i = threadIdx.x; i < sc.n_prims; i += JP_BLOCK) s_meta[i] = sc.meta[i];
 	}
-	if (kTab || kPrims) __syncthreads();
+	if (threadIdx.x == 0) { s_ctr[0] = 0; s_ctr[1] = 0; s_ctr[2] = 0; }
+	__syncthreads();
 	const float4* lights = kTab ? (const float4*)s_lights : sc.lights;
 	const float4* mats = kTab ? (const float4*)s_mats : sc.mats;
 	const int* mat_type = kTab ? (const int*)s_mtype : sc.mat_type;
 	const float4* prims = kPrims ? (const float4*)s_prims : sc.prims;
 	const int4* meta_t = kPrims ? (const int4*)s_meta : sc.meta;
 	const unsigned int rbase = b * q.R;
-	unsigned int run_q = 0, run_sh = 0;                           // block-uniform fill of this block's output regions
 	const unsigned int tile = kSort ? (unsigned int)JP_SHADE_TILE : n;
 	for (unsigned int t0 = 0; t0 < n; t0 += tile)
 	{
@@ -387,16 +397,21 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 		}
 		tile_partition<kRPT, JP_SHADE_CLASSES>(key, (unsigned int)rc.class_mask, s_cnt, s_idx);
 	}
-	// software prefetch of the next chunk's path records
+	// The tile is shaded in 64-path chunks that the waves take from an LDS counter: a wave with expensive paths (a chunk of the
+	// microfacet class) takes fewer chunks, and no wave waits for another before the end of the tile.  The records of the chunk
+	// a wave takes next are fetched while it shades the current one (software prefetch).
 	float4 ro_n = make_float4(0, 0, 0, 0), rd_n = ro_n, rb_n = ro_n; float2 h_n = make_float2(0, 0);
-	if (threadIdx.x < count) { const unsigned int i0 = rbase + t0 + (kSort ? (unsigned int)s_idx[threadIdx.x] : threadIdx.x); ro_n = q.ray_o[cur][i0]; rd_n = q.ray_d[cur][i0]; rb_n = q.beta[cur][i0]; h_n = q.hit[i0]; }
-	for (unsigned int j0 = 0; j0 < count; j0 += JP_BLOCK)
+	unsigned int c0 = wave_take(&s_ctr[0], 1u) * 64u;            // wave-uniform: first tile position of the wave's chunk
+	if (c0 + lane < count) { const unsigned int pos = c0 + lane, i0 = rbase + t0 + (kSort ? (unsigned int)s_idx[pos] : pos); ro_n = q.ray_o[cur][i0]; rd_n = q.ray_d[cur][i0]; rb_n = q.beta[cur][i0]; h_n = q.hit[i0]; }
+	while (c0 < count)
 	{
-		const bool valid = j0 + threadIdx.x < count;
+		const bool valid = c0 + lane < count;
 		const float4 ro = ro_n, rd = rd_n, rb = rb_n; const float2 h = h_n;
-		if (j0 + JP_BLOCK + threadIdx.x < count)
+		c0 = wave_take(&s_ctr[0], 1u) * 64u;
+		if (c0 + lane < count)
 		{
-			const unsigned int i1 = rbase + t0 + (kSort ? (unsigned int)s_idx[j0 + JP_BLOCK + threadIdx.x] : j0 + JP_BLOCK + threadIdx.x);
+			const unsigned int pos = c0 + lane;
+			const unsigned int i1 = rbase + t0 + (kSort ? (unsigned int)s_idx[pos] : pos);
 			ro_n = q.ray_o[cur][i1]; rd_n = q.ray_d[cur][i1]; rb_n = q.beta[cur][i1]; h_n = q.hit[i1];
 		}
 		bool shaded = false, wantNee = false, alive = false;
@@ -474,7 +489,11 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 		}
 		// ---- next-event estimation (integrator.cc:357-372) ----
 		unsigned int qs = 0;
-		if (!kStage) { unsigned int tot_sh; qs = rbase + run_sh + block_prefix(wantNee, s_tmp, tot_sh); run_sh += tot_sh; }
+		if (!kStage)
+		{
+			const unsigned long long mn = __ballot(wantNee);
+			if (mn) qs = rbase + wave_take(&s_ctr[2], (unsigned int)__popcll(mn)) + (unsigned int)__popcll(mn & ((1ull << lane) - 1ull));
+		}
 		V3 nd = d, nbeta = beta; int nbounce = bounce; bool nspec = spec;
 		V3 wo = mk(0, 0, 1);
 		int k = 0;
@@ -549,14 +568,17 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				nd = bs.wi; nbounce = bounce + 1;
 			}
 		}
-		// ---- compact survivors into the next ray queue (and, when staged, the shadow entries): one barrier per chunk ----
-		unsigned int j;
+		// ---- compact survivors into the next ray queue (and, when staged, the shadow entries): the wave takes room for its survivors
+		// from the block's fill counters (no barrier; the order of the waves' pieces in the region is whatever order they arrive in,
+		// which no result depends on: every path owns its slot and its radiance sum) ----
+		unsigned int j = 0;
+		const unsigned long long lt = (1ull << lane) - 1ull;
+		const unsigned long long ma = __ballot(alive);
+		if (ma) j = rbase + wave_take(&s_ctr[1], (unsigned int)__popcll(ma)) + (unsigned int)__popcll(ma & lt);
 		if (kStage)
 		{
-			unsigned int pq, tq, ps, ts;
-			block_prefix2(alive, k > 0, s_tmp2, chunk++, pq, tq, ps, ts);
-			j = rbase + run_q + pq; run_q += tq;
-			qs = rbase + run_sh + ps; run_sh += ts;
+			const unsigned long long ms = __ballot(k > 0);
+			if (ms) qs = rbase + wave_take(&s_ctr[2], (unsigned int)__popcll(ms)) + (unsigned int)__popcll(ms & lt);
 			if (k > 0)
 			{
 				q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
@@ -567,7 +589,6 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				}
 			}
 		}
-		else { unsigned int tot_q; j = rbase + run_q + block_prefix(alive, s_tmp, tot_q); run_q += tot_q; }
 		if (alive)
 		{
 			q.ray_o[nxt][j] = make_float4(p.x, p.y, p.z, __int_as_float(slot));       // SpawnRay shape.h:61-64
@@ -575,9 +596,12 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 			q.beta[nxt][j] = make_float4(nbeta.x, nbeta.y, nbeta.z, __int_as_float((int)key));
 		}
 	}
+	__syncthreads();                                              // every wave is through with the tile (s_idx, chunk counter)
+	if (threadIdx.x == 0) s_ctr[0] = 0;                           // the next tile's partition has barriers before the first take
 	}
 	if (threadIdx.x == 0)
 	{
+		const unsigned int run_q = s_ctr[1], run_sh = s_ctr[2];
 		q.blk_q[nxt][b] = run_q; q.blk_sh[b] = run_sh;
 		if (run_q) atomicAdd(&cnt->n_queue[nxt], run_q);
 		if (run_sh) atomicAdd(&cnt->n_shadow, run_sh);

@@ -2,7 +2,7 @@
 jp_upload_scene / jp_render), the scene is re-uploaded per variant, films are compared bit for bit against the first variant.
   python tools/gpu_ab.py SCENE[:WxH[:SPP]] "A=1 B=2" "A=0" ...      (SCENE: cornell | cornell_lambert | bunny | misc ...)
 Prints per variant: Msamples/s with the default stream lanes, and the per-class kernel times of one single-lane frame."""
-import os, sys, time
+import hashlib, os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "tests")); sys.path.insert(0, REPO)
@@ -42,7 +42,7 @@ def main():
                 ref = film
             print("%-44s %s %dx%dx%d: %7.1f Msamples/s (%d lanes) | 1 lane: %7.1f ms  extend %.2f shade %.2f shadow %.2f other %.2f | rays %d/%d | film %s" % (
                 v or "(default)", name, W, Hh, spp, W * Hh * spp / dt / 1e6, lanes, c.render_ms, c.extend_ms, c.shade_ms, c.shadow_ms, c.other_ms,
-                c.closest_rays, c.shadow_rays, same), flush=True)
+                c.closest_rays, c.shadow_rays, same + " sha1 " + hashlib.sha1(film.tobytes()).hexdigest()[:12]), flush=True)
             ctx.close()
         finally:
             for k in kv:
