@@ -335,14 +335,19 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend(SceneView sc, Queues q, int
 // (measured on the reference's Cornell scene: k_shade 3124 -> wave64 instructions per 64 paths at lane utilisation 0.42 before).
 // The partition is stable, so the big class still reads its records almost in queue order.  Every path computes exactly what it
 // computed before; only the order inside this block's output regions changes.
-#define JP_SHADE_TILE 1024
+#ifndef JP_SHADE_TILE
+#define JP_SHADE_TILE 8192
+#endif
 #define JP_SHADE_CLASSES 6
 template <bool kTab, bool kPrims, bool kStage, bool kSort>
 __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, RenderConst rc, int cur, DevCounters* cnt)
 {
-	constexpr int kRPT = JP_SHADE_TILE / JP_BLOCK, kSeg = kRPT * (JP_BLOCK / 64);       // (pass, wave) segments of a tile, in queue order
+	constexpr int kWaves = JP_BLOCK / 64, kMaxSeg = (JP_SHADE_TILE / JP_BLOCK) * kWaves;  // (pass, wave) segments of a tile, in queue order
+	static_assert(JP_SHADE_TILE % JP_BLOCK == 0 && JP_SHADE_TILE <= 65536, "k_shade: tile positions are 16-bit");
 	__shared__ unsigned short s_idx[kSort ? JP_SHADE_TILE : 1];
-	__shared__ unsigned int s_cnt[kSort ? JP_SHADE_CLASSES * kSeg : 1];
+	__shared__ unsigned char s_key[kSort ? JP_SHADE_TILE : 1];
+	__shared__ unsigned int s_cnt[kSort ? JP_SHADE_CLASSES * kMaxSeg : 1];
+	__shared__ unsigned int s_wsum[kWaves];
 	__shared__ unsigned int s_ctr[3];      // [0] next 64-path chunk of the tile; [1], [2] fill of this block's ray / shadow output regions
 	const unsigned int lane = threadIdx.x & 63u;
 	float4* s_lights = s_dyn;
@@ -376,44 +381,112 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 	const float4* prims = kPrims ? (const float4*)s_prims : sc.prims;
 	const int4* meta_t = kPrims ? (const int4*)s_meta : sc.meta;
 	const unsigned int rbase = b * q.R;
-	const unsigned int tile = kSort ? (unsigned int)JP_SHADE_TILE : n;
-	for (unsigned int t0 = 0; t0 < n; t0 += tile)
-	{
-	const unsigned int count = n - t0 < tile ? n - t0 : tile;
+	const unsigned int t0 = 0, count = n;                        // one tile: the host keeps R <= JP_SHADE_TILE for the sorted variant
 	if (kSort)
 	{   // ---- stable partition of the tile's paths by material class: s_idx[sorted position] = position in the tile ----
-		unsigned int key[kRPT];
-		#pragma unroll
-		for (int r = 0; r < kRPT; r++)
+		// Two sweeps over the tile (the whole region of the block as a rule: one partition and one closing barrier per launch):
+		// count per (class, pass, wave) with wave ballots, one block-wide exclusive scan of the counters in class-major order,
+		// then every entry goes to its class's base + its rank in its (pass, wave) segment.  Stable, no atomics.
+		constexpr unsigned int seg = kMaxSeg, nctr = JP_SHADE_CLASSES * kMaxSeg;
+		const unsigned int tid = threadIdx.x;
+		const unsigned int plane = tid & 63u, wave = tid >> 6, npass = (count + JP_BLOCK - 1) / JP_BLOCK;
+		const unsigned long long ltm = (1ull << plane) - 1ull;
+		#pragma unroll 1
+		for (unsigned int r0 = 0; r0 < npass; r0 += 4)
 		{
-			const unsigned int j = r * JP_BLOCK + threadIdx.x;
-			key[r] = JP_SHADE_CLASSES;                               // beyond the tile: no class
-			if (j < count)
+			int pi[4];
+			#pragma unroll
+			for (int u = 0; u < 4; u++)
 			{
-				const int pi = __float_as_int(q.hit[rbase + t0 + j].y);
-				int m = -1; if (pi >= 0) m = meta_t[pi].y;
-				key[r] = m >= 0 ? 1u + (unsigned int)mat_type[m] : 0u;
+				const unsigned int j = (r0 + u) * JP_BLOCK + tid;
+				pi[u] = j < count ? __float_as_int(q.hit[rbase + t0 + j].y) : -2;
+			}
+			#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				const unsigned int r = r0 + u;
+				if (r >= npass) break;
+				unsigned int key = JP_SHADE_CLASSES;                     // beyond the tile: no class
+				if (pi[u] != -2)
+				{
+					int m = -1; if (pi[u] >= 0) m = meta_t[pi[u]].y;
+					key = m >= 0 ? 1u + (unsigned int)mat_type[m] : 0u;
+				}
+				s_key[r * JP_BLOCK + tid] = (unsigned char)key;
+				#pragma unroll
+				for (int c = 0; c < JP_SHADE_CLASSES; c++)
+				{
+					unsigned int nc = 0;
+					if ((rc.class_mask >> c) & 1) nc = (unsigned int)__popcll(__ballot(key == (unsigned int)c));
+					if (plane == 0) s_cnt[c * seg + r * kWaves + wave] = nc;
+				}
 			}
 		}
-		tile_partition<kRPT, JP_SHADE_CLASSES>(key, (unsigned int)rc.class_mask, s_cnt, s_idx);
+		__syncthreads();
+		{   // exclusive scan of the nctr <= 3 * JP_BLOCK counters: three per thread, wave scan, wave totals through LDS
+			static_assert(JP_SHADE_CLASSES * kMaxSeg <= 3 * JP_BLOCK, "k_shade: three counters per thread");
+			unsigned int v[3], t = 0;
+			#pragma unroll
+			for (int i = 0; i < 3; i++)
+			{   // counters of passes beyond the tile's last one were not written: they count nothing
+				const unsigned int at = 3 * tid + i;
+				v[i] = (at < nctr && (at % seg) / kWaves < npass) ? s_cnt[at] : 0u; t += v[i];
+			}
+			unsigned int incl = t;
+			#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) { const unsigned int o = __shfl_up(incl, off); if (plane >= (unsigned int)off) incl += o; }
+			if (plane == 63) s_wsum[wave] = incl;
+			__syncthreads();
+			unsigned int base = incl - t;
+			#pragma unroll
+			for (int w = 0; w < kWaves; w++) if ((unsigned int)w < wave) base += s_wsum[w];
+			#pragma unroll
+			for (int i = 0; i < 3; i++) { const unsigned int at = 3 * tid + i; if (at < nctr) s_cnt[at] = base; base += v[i]; }
+		}
+		__syncthreads();
+		#pragma unroll 1
+		for (unsigned int r = 0; r < npass; r++)
+		{
+			const unsigned int key = s_key[r * JP_BLOCK + tid];
+			unsigned int pre = 0;
+			#pragma unroll
+			for (int c = 0; c < JP_SHADE_CLASSES; c++)
+			{
+				if (!((rc.class_mask >> c) & 1)) continue;
+				const unsigned long long m = __ballot(key == (unsigned int)c);
+				if (key == (unsigned int)c) pre = (unsigned int)__popcll(m & ltm);
+			}
+			if (key < JP_SHADE_CLASSES) s_idx[s_cnt[key * seg + r * kWaves + wave] + pre] = (unsigned short)(r * JP_BLOCK + tid);
+		}
+		__syncthreads();
 	}
 	// The tile is shaded in 64-path chunks that the waves take from an LDS counter: a wave with expensive paths (a chunk of the
 	// microfacet class) takes fewer chunks, and no wave waits for another before the end of the tile.  The records of the chunk
 	// a wave takes next are fetched while it shades the current one (software prefetch).
 	float4 ro_n = make_float4(0, 0, 0, 0), rd_n = ro_n, rb_n = ro_n; float2 h_n = make_float2(0, 0);
-	unsigned int c0 = wave_take(&s_ctr[0], 1u) * 64u;            // wave-uniform: first tile position of the wave's chunk
-	if (c0 + lane < count) { const unsigned int pos = c0 + lane, i0 = rbase + t0 + (kSort ? (unsigned int)s_idx[pos] : pos); ro_n = q.ray_o[cur][i0]; rd_n = q.ray_d[cur][i0]; rb_n = q.beta[cur][i0]; h_n = q.hit[i0]; }
-	while (c0 < count)
+	// Chunks are taken from the END of the sorted tile: the expensive classes (plastic, metal) sort last, and taking them first
+	// leaves the cheap chunks to even out the waves before the barrier at the end of the tile.
+	const unsigned int nch = (count + 63u) >> 6;
+	unsigned int tk = wave_take(&s_ctr[0], 1u);                  // wave-uniform
+	unsigned int c0 = (nch - 1u - tk) << 6;                      // first tile position of the wave's chunk (meaningful while tk < nch)
+	if (tk < nch && c0 + lane < count) { const unsigned int pos = c0 + lane, i0 = rbase + t0 + (kSort ? (unsigned int)s_idx[pos] : pos); ro_n = q.ray_o[cur][i0]; rd_n = q.ray_d[cur][i0]; rb_n = q.beta[cur][i0]; h_n = q.hit[i0]; }
+	while (tk < nch)
 	{
 		const bool valid = c0 + lane < count;
+#ifdef JP_SHADE_NO_PREFETCH
+		if (valid) { const unsigned int pos = c0 + lane, i0 = rbase + t0 + (kSort ? (unsigned int)s_idx[pos] : pos); ro_n = q.ray_o[cur][i0]; rd_n = q.ray_d[cur][i0]; rb_n = q.beta[cur][i0]; h_n = q.hit[i0]; }
 		const float4 ro = ro_n, rd = rd_n, rb = rb_n; const float2 h = h_n;
-		c0 = wave_take(&s_ctr[0], 1u) * 64u;
-		if (c0 + lane < count)
+		tk = wave_take(&s_ctr[0], 1u); c0 = (nch - 1u - tk) << 6;
+#else
+		const float4 ro = ro_n, rd = rd_n, rb = rb_n; const float2 h = h_n;
+		tk = wave_take(&s_ctr[0], 1u); c0 = (nch - 1u - tk) << 6;
+		if (tk < nch && c0 + lane < count)
 		{
 			const unsigned int pos = c0 + lane;
 			const unsigned int i1 = rbase + t0 + (kSort ? (unsigned int)s_idx[pos] : pos);
 			ro_n = q.ray_o[cur][i1]; rd_n = q.ray_d[cur][i1]; rb_n = q.beta[cur][i1]; h_n = q.hit[i1];
 		}
+#endif
 		bool shaded = false, wantNee = false, alive = false;
 		V3 o = mk(0, 0, 0), d = mk(0, 0, 1), beta = mk(0, 0, 0), p = mk(0, 0, 0), N = mk(0, 0, 1);
 		int slot = 0, bounce = 0; bool spec = false; unsigned int dim = 0; uint32_t key = 0;
@@ -596,9 +669,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 			q.beta[nxt][j] = make_float4(nbeta.x, nbeta.y, nbeta.z, __int_as_float((int)key));
 		}
 	}
-	__syncthreads();                                              // every wave is through with the tile (s_idx, chunk counter)
-	if (threadIdx.x == 0) s_ctr[0] = 0;                           // the next tile's partition has barriers before the first take
-	}
+	__syncthreads();                                              // every wave has added its survivors to the fill counters
 	if (threadIdx.x == 0)
 	{
 		const unsigned int run_q = s_ctr[1], run_sh = s_ctr[2];
@@ -1840,8 +1911,11 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		size_t tab = ((size_t)2 * s->n_lights + (size_t)4 * s->n_materials) * sizeof(float4) + (size_t)s->n_materials * sizeof(int) + 16;
 		c->tables_in_lds = tab <= 16 * 1024;
 		c->shade_lds_bytes = c->tables_in_lds ? tab + (c->scene_in_lds ? n4prims * sizeof(float4) + nmeta * sizeof(int4) : 0) : 0;
-		c->stage_nee = c->tables_in_lds && std::max(1, planes) <= 4;
-		if (c->stage_nee) c->shade_lds_bytes += 16 + (size_t)std::max(1, planes) * 2 * JP_BLOCK * sizeof(float4);
+		// k_shade's static LDS (tile index, keys, counters of the material sort) + tables + staging must stay within 64 KB a workgroup
+		const size_t shade_static = (size_t)JP_SHADE_TILE * 3 + (size_t)JP_SHADE_CLASSES * (JP_SHADE_TILE / JP_BLOCK) * (JP_BLOCK / 64) * 4 + 128;
+		const size_t stage_bytes = 16 + (size_t)std::max(1, planes) * 2 * JP_BLOCK * sizeof(float4);
+		c->stage_nee = c->tables_in_lds && std::max(1, planes) <= 4 && shade_static + c->shade_lds_bytes + stage_bytes <= 64 * 1024;
+		if (c->stage_nee) c->shade_lds_bytes += stage_bytes;
 	}
 	c->n_planes = std::max(1, planes);
 	{   // material sort in k_shade: pays when the primitives carry more than one material kind (JETPBRT_SHADE_SORT = 0 / 1 forces it)
@@ -1951,7 +2025,8 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 		if ((long long)sbatch * npix > (long long)PMAX) return fail(JP_ERR_UNSUPPORTED, "jp_render: shard too large for one batch");
 		const unsigned int P = (unsigned int)((long long)sbatch * npix);
 		const unsigned int nchunks = (P + JP_BLOCK - 1) / JP_BLOCK;
-		const unsigned int G = std::max(1u, std::min(nchunks, (unsigned int)(c->n_cus * c->blocks_per_cu)));   // one region per workgroup
+		unsigned int G = std::max(1u, std::min(nchunks, (unsigned int)(c->n_cus * c->blocks_per_cu)));   // one region per workgroup
+		if (c->shade_sort) G = std::max(G, (nchunks + JP_SHADE_TILE / JP_BLOCK - 1) / (JP_SHADE_TILE / JP_BLOCK));   // k_shade<kSort> partitions a whole region in LDS
 		const unsigned int R = ((nchunks + G - 1) / G) * JP_BLOCK;
 		const unsigned int cap = G * R;
 		int st = ensure_queues(c, cap, c->n_planes, G); if (st != JP_OK) return st;
