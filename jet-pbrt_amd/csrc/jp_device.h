@@ -61,6 +61,7 @@ struct SceneView
 	const int* mat_type; int n_mats;
 	const float4* lights;                   // 2 x float4 per light: (radiance, type bits), then AREA (device prim bits, 1/area, -, -), POINT / DIRECTION (vec xyz, -)
 	int n_lights;
+	const float4* shade_tab;                // k_shade's LDS tables as one array in LDS order: lights | mats | mat_type (padded to 16 B) [| prims | meta]
 	float3 env_sum;                         // sum of the infinite lights' radiance in Lights() order (light.h:300-303)
 	int n_env;
 	float world_radius;

@@ -335,6 +335,14 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend(SceneView sc, Queues q, int
 // (measured on the reference's Cornell scene: k_shade 3124 -> wave64 instructions per 64 paths at lane utilisation 0.42 before).
 // The partition is stable, so the big class still reads its records almost in queue order.  Every path computes exactly what it
 // computed before; only the order inside this block's output regions changes.
+// -DJP_SHADE_TIMING (diagnostic builds only, tools/shade_timing.py): every wave of k_shade adds the shader-clock cycles it spends
+// in each section of the kernel to g_shade_t; jp_dbg_shade_timing reads and clears the sums.
+#ifdef JP_SHADE_TIMING
+__device__ unsigned long long g_shade_t[16];
+#define JP_TS(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[i] += t_ - t_last; t_last = t_; } while (0)
+#else
+#define JP_TS(i) do { } while (0)
+#endif
 #ifndef JP_SHADE_TILE
 #define JP_SHADE_TILE 8192
 #endif
@@ -342,6 +350,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend(SceneView sc, Queues q, int
 template <bool kTab, bool kPrims, bool kStage, bool kSort>
 __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, RenderConst rc, int cur, DevCounters* cnt)
 {
+	static_assert(kTab || !kPrims, "k_shade: primitive records in LDS only together with the tables");
 	constexpr int kWaves = JP_BLOCK / 64, kMaxSeg = (JP_SHADE_TILE / JP_BLOCK) * kWaves;  // (pass, wave) segments of a tile, in queue order
 	static_assert(JP_SHADE_TILE % JP_BLOCK == 0 && JP_SHADE_TILE <= 65536, "k_shade: tile positions are 16-bit");
 	__shared__ unsigned short s_idx[kSort ? JP_SHADE_TILE : 1];
@@ -350,28 +359,32 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 	__shared__ unsigned int s_wsum[kWaves];
 	__shared__ unsigned int s_ctr[3];      // [0] next 64-path chunk of the tile; [1], [2] fill of this block's ray / shadow output regions
 	const unsigned int lane = threadIdx.x & 63u;
+	// LDS tables in the order of sc.shade_tab: lights | mats | mat_type (padded to 16 B) | prims | meta
+	const int n_tab = 2 * sc.n_lights + 4 * sc.n_mats + (sc.n_mats + 3) / 4, n_tab_all = n_tab + (kPrims ? 5 * sc.n_prims : 0);
 	float4* s_lights = s_dyn;
 	float4* s_mats = s_lights + 2 * sc.n_lights;
-	float4* s_prims = s_mats + 4 * sc.n_mats;
+	int* s_mtype = (int*)(s_mats + 4 * sc.n_mats);
+	float4* s_prims = s_dyn + n_tab;
 	int4* s_meta = (int4*)(s_prims + 4 * sc.n_prims);
-	int* s_mtype = kPrims ? (int*)(s_meta + sc.n_prims) : (int*)s_prims;
-	// [(2k, 2k+1) * 256 + tid], behind the tables (an index into s_dyn, not a cast through an integer: the pointer keeps its LDS
-	// address space, so the staging is ds_write / ds_read -- as flat accesses its reads sat behind `s_waitcnt vmcnt(0)`, i.e. behind
-	// the acknowledgement of every store issued before them)
-	float4* s_stage = s_dyn + (2 * sc.n_lights + 4 * sc.n_mats + (kPrims ? 5 * sc.n_prims : 0) + (sc.n_mats + 3) / 4) + threadIdx.x;
+	// NEE staging [(2k, 2k+1) * 256 + tid], behind the tables (an index into s_dyn, not a cast through an integer: the pointer keeps
+	// its LDS address space, so the staging is ds_write / ds_read -- as flat accesses its reads sat behind `s_waitcnt vmcnt(0)`,
+	// i.e. behind the acknowledgement of every store issued before them)
+	float4* s_stage = s_dyn + n_tab_all + threadIdx.x;
 	const unsigned int b = blockIdx.x, n = q.blk_q[cur][b];
 	const int nxt = cur ^ 1;
 	if (n == 0) { if (threadIdx.x == 0) { q.blk_q[nxt][b] = 0; q.blk_sh[b] = 0; } return; }
+#ifdef JP_SHADE_TIMING
+	unsigned long long t_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, t_last = __builtin_amdgcn_s_memtime();
+#endif
 	if (kTab)
-	{
-		for (int i = threadIdx.x; i < 2 * sc.n_lights; i += JP_BLOCK) s_lights[i] = sc.lights[i];
-		for (int i = threadIdx.x; i < 4 * sc.n_mats; i += JP_BLOCK) s_mats[i] = sc.mats[i];
-		for (int i = threadIdx.x; i < sc.n_mats; i += JP_BLOCK) s_mtype[i] = sc.mat_type[i];
-	}
-	if (kPrims)
-	{
-		for (int i = threadIdx.x; i < 4 * sc.n_prims; i += JP_BLOCK) s_prims[i] = sc.prims[i];
-		for (int i = threadIdx.x; i < sc.n_prims; i += JP_BLOCK) s_meta[i] = sc.meta[i];
+	{   // one array, one sweep, two loads in flight per thread: a single round trip to memory as a rule (five dependent copy loops
+		// over five arrays were 13 % of a wave's lifetime on the Cornell box)
+		for (int i = threadIdx.x; i < n_tab_all; i += 2 * JP_BLOCK)
+		{
+			const bool two = i + JP_BLOCK < n_tab_all;
+			const float4 a = sc.shade_tab[i], c2 = two ? sc.shade_tab[i + JP_BLOCK] : a;
+			s_dyn[i] = a; if (two) s_dyn[i + JP_BLOCK] = c2;
+		}
 	}
 	if (threadIdx.x == 0) { s_ctr[0] = 0; s_ctr[1] = 0; s_ctr[2] = 0; }
 	__syncthreads();
@@ -382,6 +395,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 	const int4* meta_t = kPrims ? (const int4*)s_meta : sc.meta;
 	const unsigned int rbase = b * q.R;
 	const unsigned int t0 = 0, count = n;                        // one tile: the host keeps R <= JP_SHADE_TILE for the sorted variant
+	JP_TS(0);                                                     // [0] table staging
 	if (kSort)
 	{   // ---- stable partition of the tile's paths by material class: s_idx[sorted position] = position in the tile ----
 		// Two sweeps over the tile (the whole region of the block as a rule: one partition and one closing barrier per launch):
@@ -466,6 +480,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 	float4 ro_n = make_float4(0, 0, 0, 0), rd_n = ro_n, rb_n = ro_n; float2 h_n = make_float2(0, 0);
 	// Chunks are taken from the END of the sorted tile: the expensive classes (plastic, metal) sort last, and taking them first
 	// leaves the cheap chunks to even out the waves before the barrier at the end of the tile.
+	JP_TS(1);                                                     // [1] partition
 	const unsigned int nch = (count + 63u) >> 6;
 	unsigned int tk = wave_take(&s_ctr[0], 1u);                  // wave-uniform
 	unsigned int c0 = (nch - 1u - tk) << 6;                      // first tile position of the wave's chunk (meaningful while tk < nch)
@@ -473,6 +488,11 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 	while (tk < nch)
 	{
 		const bool valid = c0 + lane < count;
+#ifdef JP_SHADE_TIMING
+		JP_TS(2);                                                 // [2] loop overhead
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		JP_TS(3);                                                 // [3] wait for the prefetched records (and for the stores before them)
+#endif
 #ifdef JP_SHADE_NO_PREFETCH
 		if (valid) { const unsigned int pos = c0 + lane, i0 = rbase + t0 + (kSort ? (unsigned int)s_idx[pos] : pos); ro_n = q.ray_o[cur][i0]; rd_n = q.ray_d[cur][i0]; rb_n = q.beta[cur][i0]; h_n = q.hit[i0]; }
 		const float4 ro = ro_n, rd = rd_n, rb = rb_n; const float2 h = h_n;
@@ -560,6 +580,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				}
 			}
 		}
+		JP_TS(4);                                                 // [4] prefetch issue, hit decode, emission, closure, frame
 		// ---- next-event estimation (integrator.cc:357-372) ----
 		unsigned int qs = 0;
 		if (!kStage)
@@ -610,6 +631,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				if (!kStage) q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
 			}
 		}
+		JP_TS(5);                                                 // [5] next-event estimation
 #ifdef JP_DBG_SKIP_SAMPLE
 		if (false)
 #else
@@ -644,14 +666,19 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 		// ---- compact survivors into the next ray queue (and, when staged, the shadow entries): the wave takes room for its survivors
 		// from the block's fill counters (no barrier; the order of the waves' pieces in the region is whatever order they arrive in,
 		// which no result depends on: every path owns its slot and its radiance sum) ----
+		JP_TS(6);                                                 // [6] BSDF sample, Russian roulette
 		unsigned int j = 0;
 		const unsigned long long lt = (1ull << lane) - 1ull;
 		const unsigned long long ma = __ballot(alive);
-		if (ma) j = rbase + wave_take(&s_ctr[1], (unsigned int)__popcll(ma)) + (unsigned int)__popcll(ma & lt);
 		if (kStage)
-		{
+		{   // both fills in one LDS atomic: rays in the low half, shadow entries in the high half (a region holds <= 8192 < 2^16)
 			const unsigned long long ms = __ballot(k > 0);
-			if (ms) qs = rbase + wave_take(&s_ctr[2], (unsigned int)__popcll(ms)) + (unsigned int)__popcll(ms & lt);
+			if (ma | ms)
+			{
+				const unsigned int base = wave_take(&s_ctr[1], (unsigned int)__popcll(ma) | ((unsigned int)__popcll(ms) << 16));
+				j = rbase + (base & 0xffffu) + (unsigned int)__popcll(ma & lt);
+				qs = rbase + (base >> 16) + (unsigned int)__popcll(ms & lt);
+			}
 			if (k > 0)
 			{
 				q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
@@ -668,11 +695,18 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 			q.ray_d[nxt][j] = make_float4(nd.x, nd.y, nd.z, __int_as_float(MK_FLAGS(nbounce, nspec, dim)));
 			q.beta[nxt][j] = make_float4(nbeta.x, nbeta.y, nbeta.z, __int_as_float((int)key));
 		}
+		JP_TS(7);                                                 // [7] room in the output regions, store issue
 	}
+	JP_TS(2);
 	__syncthreads();                                              // every wave has added its survivors to the fill counters
+	JP_TS(8);                                                     // [8] closing barrier
+#ifdef JP_SHADE_TIMING
+	if (lane == 0) for (int i = 0; i < 9; i++) atomicAdd(&g_shade_t[i], t_acc[i]);
+	if (lane == 0) atomicAdd(&g_shade_t[9], 1ull);
+#endif
 	if (threadIdx.x == 0)
 	{
-		const unsigned int run_q = s_ctr[1], run_sh = s_ctr[2];
+		const unsigned int run_q = kStage ? (s_ctr[1] & 0xffffu) : s_ctr[1], run_sh = kStage ? (s_ctr[1] >> 16) : s_ctr[2];
 		q.blk_q[nxt][b] = run_q; q.blk_sh[b] = run_sh;
 		if (run_q) atomicAdd(&cnt->n_queue[nxt], run_q);
 		if (run_sh) atomicAdd(&cnt->n_shadow, run_sh);
@@ -738,6 +772,8 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_sort(SceneView sc, Queues q
 	__shared__ unsigned short s_idx[JP_SORT_TILE];
 	__shared__ unsigned int s_cnt[JP_SORT_CLASSES * kRPT * (JP_BLOCK / 64)];
 	__shared__ u64 s_mask[kMode == 2 ? JP_SORT_TILE : 1];           // mode 2: the box-phase result, so phase 1 runs once
+	__shared__ unsigned int s_take;
+	if (threadIdx.x == 0) s_take = 0;
 	SceneAccess<kMode> acc(sc, depth);
 	const unsigned int b = blockIdx.x, n = q.blk_q[cur][b], rbase = b * q.R;
 	if (b == 0 && threadIdx.x == 0) { cnt->closest += cnt->n_queue[cur]; cnt->n_queue[cur ^ 1] = 0; cnt->n_shadow = 0; }
@@ -767,13 +803,18 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_sort(SceneView sc, Queues q
 		tile_partition<kRPT, JP_SORT_CLASSES>(key, 0x3fu, s_cnt, s_idx);
 		// software prefetch: the next pass' ray is requested before this pass' traversal
 		float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 1, 0); unsigned int jn = 0;
-		if (threadIdx.x < count) { jn = s_idx[threadIdx.x]; ro = q.ray_o[cur][rbase + t0 + jn]; rd = q.ray_d[cur][rbase + t0 + jn]; }
+		// 64-ray chunks, taken by the waves from an LDS counter, most expected work first (the classes sort ascending): the waves
+		// reach the barrier at the end of the tile together
+		const unsigned int nch = (count + 63u) >> 6, lane = threadIdx.x & 63u;
+		unsigned int tk = wave_take(&s_take, 1u), c0 = (nch - 1u - tk) << 6;
+		if (tk < nch && c0 + lane < count) { jn = s_idx[c0 + lane]; ro = q.ray_o[cur][rbase + t0 + jn]; rd = q.ray_d[cur][rbase + t0 + jn]; }
 		#pragma unroll 1
-		for (unsigned int p0 = 0; p0 < count; p0 += JP_BLOCK)
+		while (tk < nch)
 		{
-			const unsigned int pos = p0 + threadIdx.x, j = jn;
+			const unsigned int pos = c0 + lane, j = jn;
 			const float4 co = ro, cd = rd;
-			if (pos + JP_BLOCK < count) { jn = s_idx[pos + JP_BLOCK]; ro = q.ray_o[cur][rbase + t0 + jn]; rd = q.ray_d[cur][rbase + t0 + jn]; }
+			tk = wave_take(&s_take, 1u); c0 = (nch - 1u - tk) << 6;
+			if (tk < nch && c0 + lane < count) { jn = s_idx[c0 + lane]; ro = q.ray_o[cur][rbase + t0 + jn]; rd = q.ray_d[cur][rbase + t0 + jn]; }
 			if (pos < count)
 			{
 				float tmax = JP_INF;                                     // FRay defaults geometry.h:399: min_t 0.001, max_t infinity
@@ -789,6 +830,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_sort(SceneView sc, Queues q
 			}
 		}
 		__syncthreads();                                             // s_idx / s_mask are rewritten by the next tile
+		if (threadIdx.x == 0) s_take = 0;                            // (the partition's barriers come before the next take)
 	}
 	for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off);
 	if ((threadIdx.x & 63) == 0 && h) atomicAdd(&cnt->closest_hit, (unsigned long long)h);
@@ -944,6 +986,8 @@ __global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow_sort(SceneView sc, Queue
 	__shared__ unsigned short s_idx[JP_SORT_TILE];
 	__shared__ unsigned int s_cnt[JP_SORT_CLASSES * kRPT * (JP_BLOCK / 64)];
 	__shared__ u64 s_mask[kMode == 2 ? 2 * JP_SORT_TILE : 1];       // mode 2: box-phase masks of the entry's first two rays (further rays redo the phase)
+	__shared__ unsigned int s_take;
+	if (threadIdx.x == 0) s_take = 0;
 	SceneAccess<kMode> acc(sc, depth);
 	const unsigned int b = blockIdx.x, E = q.blk_sh[b], rbase = b * q.R;
 	const bool w64 = sc.n_prims > 32;
@@ -981,13 +1025,16 @@ __global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow_sort(SceneView sc, Queue
 		}
 		tile_partition<kRPT, JP_SORT_CLASSES>(key, 0x3fu, s_cnt, s_idx);
 		float4 so_n = make_float4(0, 0, 0, 0), sd_n = make_float4(0, 0, 1, 0); unsigned int jn = 0;
-		if (threadIdx.x < count) { jn = s_idx[threadIdx.x]; so_n = q.sh_o[rbase + e0 + jn]; sd_n = q.sh_d[rbase + e0 + jn]; }
+		const unsigned int nch = (count + 63u) >> 6, lane = threadIdx.x & 63u;      // chunks taken most work first, as in k_extend_sort
+		unsigned int tk = wave_take(&s_take, 1u), c0 = (nch - 1u - tk) << 6;
+		if (tk < nch && c0 + lane < count) { jn = s_idx[c0 + lane]; so_n = q.sh_o[rbase + e0 + jn]; sd_n = q.sh_d[rbase + e0 + jn]; }
 		#pragma unroll 1
-		for (unsigned int p0 = 0; p0 < count; p0 += JP_BLOCK)
+		while (tk < nch)
 		{
-			const unsigned int pos = p0 + threadIdx.x, j = jn, e = rbase + e0 + j;
+			const unsigned int pos = c0 + lane, j = jn, e = rbase + e0 + j;
 			const float4 so = so_n; float4 sd = sd_n;
-			if (pos + JP_BLOCK < count) { jn = s_idx[pos + JP_BLOCK]; so_n = q.sh_o[rbase + e0 + jn]; sd_n = q.sh_d[rbase + e0 + jn]; }
+			tk = wave_take(&s_take, 1u); c0 = (nch - 1u - tk) << 6;
+			if (tk < nch && c0 + lane < count) { jn = s_idx[c0 + lane]; so_n = q.sh_o[rbase + e0 + jn]; sd_n = q.sh_d[rbase + e0 + jn]; }
 			if (pos >= count) continue;
 			const int packed = __float_as_int(so.w);
 			const int slot = packed & 0xffffff, nr = (packed >> 24) & 0xff;
@@ -1020,6 +1067,7 @@ __global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow_sort(SceneView sc, Queue
 			if (any) q.lacc[slot] = make_float4(a.x, a.y, a.z, 0.f);
 		}
 		__syncthreads();                                             // s_idx / s_mask are rewritten by the next tile
+		if (threadIdx.x == 0) s_take = 0;
 	}
 	for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); occ += __shfl_down(occ, off); }
 	if ((threadIdx.x & 63) == 0) { if (rays) atomicAdd(&cnt->shadow, (unsigned long long)rays); if (occ) atomicAdd(&cnt->shadow_occ, (unsigned long long)occ); }
@@ -1294,7 +1342,7 @@ struct JpContext
 	SceneView sv; int stack_depth = 1; bool scene_in_lds = false; size_t lds_bytes = 0, lds_bytes_shadow = 0;
 	void *d_flat = nullptr, *d_wide = nullptr, *d_cut = nullptr; bool ray_sort = false; int trav_mode = 0;
 	bool vote = false; int persist = 0;                                             // lane refill in the closest-hit traversal of large scenes (k_extend_persist): refill threshold, 0 = off
-	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr;
+	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr, *d_shade_tab = nullptr;
 	int n_planes = 1; bool has_null_material = false; int sincosf_mode = 0;
 	bool build_on_device = false; float build_ms = 0.f; int bvh_height = 0, bvh_nodes = 0;
 	bool tables_in_lds = false, stage_nee = false; size_t shade_lds_bytes = 0;
@@ -1324,7 +1372,7 @@ struct JpContext
 
 static void free_scene(JpContext* c)
 {
-	void** ps[] = { &c->d_flat, &c->d_cut, &c->d_wide, &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights };
+	void** ps[] = { &c->d_flat, &c->d_cut, &c->d_wide, &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights, &c->d_shade_tab };
 	for (void** p : ps) { if (*p) hipFree(*p); *p = nullptr; }
 	c->have_scene = false;
 }
@@ -1878,6 +1926,20 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	HIP_TRY(up(&c->d_mats, mats.data(), mats.size() * sizeof(float4)));
 	HIP_TRY(up(&c->d_mat_type, mtype.data(), mtype.size() * sizeof(int)));
 	HIP_TRY(up(&c->d_lights, lights.data(), lights.size() * sizeof(float4)));
+	{   // k_shade's LDS tables as one array (SceneView::shade_tab); the primitive part only when the host has the records
+		std::vector<float4> tabv;
+		tabv.insert(tabv.end(), lights.begin(), lights.begin() + 2 * (size_t)s->n_lights);          // exactly the counts the kernel indexes with
+		tabv.insert(tabv.end(), mats.begin(), mats.begin() + 4 * (size_t)s->n_materials);
+		const size_t at = tabv.size(); tabv.resize(at + ((size_t)s->n_materials + 3) / 4, make_float4(0, 0, 0, 0));
+		if (s->n_materials > 0) std::memcpy(&tabv[at], mtype.data(), (size_t)s->n_materials * sizeof(int));
+		if (!device_build)
+		{
+			tabv.insert(tabv.end(), prims.begin(), prims.end());
+			const size_t am = tabv.size(); tabv.resize(am + meta.size());
+			std::memcpy(&tabv[am], meta.data(), meta.size() * sizeof(int4));
+		}
+		HIP_TRY(up(&c->d_shade_tab, tabv.data(), tabv.size() * sizeof(float4)));
+	}
 	if (use_wide && !dev_wide) HIP_TRY(up(&c->d_wide, wide.data(), wide.size() * sizeof(uint32_t)));
 	if (!flat.empty()) HIP_TRY(up(&c->d_flat, flat.data(), flat.size() * sizeof(float4)));
 	if (!cut.empty()) HIP_TRY(up(&c->d_cut, cut.data(), cut.size() * sizeof(float4)));
@@ -1886,7 +1948,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.nodes = (const float4*)c->d_nodes; v.n_nodes = (int)(n4nodes / 4);
 	v.prims = (const float4*)c->d_prims; v.meta = (const int4*)c->d_meta; v.n_prims = (int)nmeta;
 	v.mats = (const float4*)c->d_mats; v.mat_type = (const int*)c->d_mat_type; v.n_mats = s->n_materials;
-	v.lights = (const float4*)c->d_lights; v.n_lights = s->n_lights;
+	v.lights = (const float4*)c->d_lights; v.n_lights = s->n_lights; v.shade_tab = (const float4*)c->d_shade_tab;
 	v.env_sum = make_float3(envsum[0], envsum[1], envsum[2]); v.n_env = nenv;
 	v.world_radius = s->world_radius; v.cam = s->camera;
 	v.flat = (const float4*)c->d_flat; v.n_flat = (int)(flat.size() / 2);
@@ -2026,7 +2088,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 		const unsigned int P = (unsigned int)((long long)sbatch * npix);
 		const unsigned int nchunks = (P + JP_BLOCK - 1) / JP_BLOCK;
 		unsigned int G = std::max(1u, std::min(nchunks, (unsigned int)(c->n_cus * c->blocks_per_cu)));   // one region per workgroup
-		if (c->shade_sort) G = std::max(G, (nchunks + JP_SHADE_TILE / JP_BLOCK - 1) / (JP_SHADE_TILE / JP_BLOCK));   // k_shade<kSort> partitions a whole region in LDS
+		G = std::max(G, (nchunks + JP_SHADE_TILE / JP_BLOCK - 1) / (JP_SHADE_TILE / JP_BLOCK));   // R <= JP_SHADE_TILE: k_shade partitions a whole region in LDS and counts its fills in 16 bits
 		const unsigned int R = ((nchunks + G - 1) / G) * JP_BLOCK;
 		const unsigned int cap = G * R;
 		int st = ensure_queues(c, cap, c->n_planes, G); if (st != JP_OK) return st;
@@ -2387,3 +2449,13 @@ int jp_trace(JpContext* c, int32_t n, const float* origin, const float* dir, con
 }
 
 } // extern "C"
+
+#ifdef JP_SHADE_TIMING
+extern "C" int jp_dbg_shade_timing(unsigned long long* out16)
+{
+	unsigned long long z[16] = { 0 };
+	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_shade_t), sizeof(z)) != hipSuccess) return -1;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(g_shade_t), z, sizeof(z)) != hipSuccess) return -1;
+	return 0;
+}
+#endif
