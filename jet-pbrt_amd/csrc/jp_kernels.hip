@@ -359,13 +359,14 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 	__shared__ unsigned int s_wsum[kWaves];
 	__shared__ unsigned int s_ctr[3];      // [0] next 64-path chunk of the tile; [1], [2] fill of this block's ray / shadow output regions
 	const unsigned int lane = threadIdx.x & 63u;
-	// LDS tables in the order of sc.shade_tab: lights | mats | mat_type (padded to 16 B) | prims | meta
-	const int n_tab = 2 * sc.n_lights + 4 * sc.n_mats + (sc.n_mats + 3) / 4, n_tab_all = n_tab + (kPrims ? 5 * sc.n_prims : 0);
+	// LDS tables in the order of sc.shade_tab: lights | mats | mat_type (padded to 16 B) | prims | meta | frames
+	const int n_tab = 2 * sc.n_lights + 4 * sc.n_mats + (sc.n_mats + 3) / 4, n_tab_all = n_tab + (kPrims ? 8 * sc.n_prims : 0);
 	float4* s_lights = s_dyn;
 	float4* s_mats = s_lights + 2 * sc.n_lights;
 	int* s_mtype = (int*)(s_mats + 4 * sc.n_mats);
 	float4* s_prims = s_dyn + n_tab;
 	int4* s_meta = (int4*)(s_prims + 4 * sc.n_prims);
+	const float4* s_frames = s_prims + 5 * sc.n_prims;           // kPrims: the shading frame of every flat primitive, 3 x float4 (n, s, t)
 	// NEE staging [(2k, 2k+1) * 256 + tid], behind the tables (an index into s_dyn, not a cast through an integer: the pointer keeps
 	// its LDS address space, so the staging is ds_write / ds_read -- as flat accesses its reads sat behind `s_waitcnt vmcnt(0)`,
 	// i.e. behind the acknowledgement of every store issued before them)
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 			bounce = FLAG_BOUNCE(flags); spec = FLAG_SPEC(flags); dim = FLAG_DIM(flags);
 			const int pi = __float_as_int(h.y);
 			const bool found = pi >= 0;
-			int mat = -1;
+			int mat = -1, hitprim = 0; bool nflip = false, tabframe = kPrims;
 			V3 Le = splat(0);
 			if (found)
 			{
@@ -528,9 +529,10 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				const int type = __float_as_int(g3.w);
 				p = o + h.x * d;                                                      // ray(distance) geometry.h:412-416
 				if (type == JP_SHAPE_TRIANGLE) N = xyz(g3);
-				else if (type == JP_SHAPE_RECTANGLE) N = dot(xyz(g3), d) <= 0 ? xyz(g3) : -xyz(g3);   // shape.h:427
+				else if (type == JP_SHAPE_RECTANGLE) { nflip = !(dot(xyz(g3), d) <= 0); N = nflip ? -xyz(g3) : xyz(g3); }   // shape.h:427
 				else if (type == JP_SHAPE_DISK) N = xyz(prims[4 * pi + 1]);                           // shape.h:214
-				else { const float4 g0 = prims[4 * pi]; N = normalize(p - xyz(g0)); }              // shape.h:521
+				else { const float4 g0 = prims[4 * pi]; N = normalize(p - xyz(g0)); tabframe = false; }   // shape.h:521
+				hitprim = pi;
 				mat = meta.y;
 				if (meta.z >= 0 && (bounce == 0 || spec))                             // primitive.h:60-63, light.h:234-238
 				{
@@ -570,7 +572,14 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 #ifdef JP_DBG_SKIP_FRAME
 					fr.n = N; fr.s = mk(N.y, N.z, N.x); fr.t = mk(N.z, N.x, N.y);
 #else
-					fr = frame_from_z(N);
+					if (kPrims && tabframe)
+					{   // FFrame(normal) geometry.h:345-349 from the table the host computed with the same operations in the same order;
+						// for the far side of a rectangle n and t change sign and s does not (every product and quotient keeps its
+						// magnitude; |n.x| > 0.99 picks the same helper axis)
+						const float4 fn = s_frames[3 * hitprim], fs = s_frames[3 * hitprim + 1], ft = s_frames[3 * hitprim + 2];
+						fr.n = nflip ? -xyz(fn) : xyz(fn); fr.s = xyz(fs); fr.t = nflip ? -xyz(ft) : xyz(ft);
+					}
+					else fr = frame_from_z(N);
 #endif
 					shaded = true;
 					wantNee = !is_delta(c);
@@ -689,6 +698,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 				}
 			}
 		}
+		else if (ma) j = rbase + wave_take(&s_ctr[1], (unsigned int)__popcll(ma)) + (unsigned int)__popcll(ma & lt);   // (shadow entries took their room before the light loop)
 		if (alive)
 		{
 			q.ray_o[nxt][j] = make_float4(p.x, p.y, p.z, __int_as_float(slot));       // SpawnRay shape.h:61-64
@@ -696,13 +706,17 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 			q.beta[nxt][j] = make_float4(nbeta.x, nbeta.y, nbeta.z, __int_as_float((int)key));
 		}
 		JP_TS(7);                                                 // [7] room in the output regions, store issue
+#ifdef JP_SHADE_TIMING
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		JP_TS(9);                                                 // [9] memory wait at the end of the chunk
+#endif
 	}
 	JP_TS(2);
 	__syncthreads();                                              // every wave has added its survivors to the fill counters
 	JP_TS(8);                                                     // [8] closing barrier
 #ifdef JP_SHADE_TIMING
-	if (lane == 0) for (int i = 0; i < 9; i++) atomicAdd(&g_shade_t[i], t_acc[i]);
-	if (lane == 0) atomicAdd(&g_shade_t[9], 1ull);
+	if (lane == 0) for (int i = 0; i < 10; i++) atomicAdd(&g_shade_t[i], t_acc[i]);
+	if (lane == 0) atomicAdd(&g_shade_t[15], 1ull);
 #endif
 	if (threadIdx.x == 0)
 	{
@@ -1937,6 +1951,19 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 			tabv.insert(tabv.end(), prims.begin(), prims.end());
 			const size_t am = tabv.size(); tabv.resize(am + meta.size());
 			std::memcpy(&tabv[am], meta.data(), meta.size() * sizeof(int4));
+			// FFrame(normal) (geometry.h:345-349, 371-376) of every flat primitive's stored normal, operation by operation as
+			// frame_from_z does it on the device (this file is compiled with -ffp-contract=off for the host too)
+			auto hnorm = [](HV3 a) { const float l = hlen(a); HV3 r = { a.x / l, a.y / l, a.z / l }; return r; };
+			for (size_t pi = 0; pi < meta.size(); pi++)
+			{
+				const float4 g3 = prims[4 * pi + 3], g1 = prims[4 * pi + 1];
+				int type; std::memcpy(&type, &g3.w, 4);
+				const HV3 nn = type == JP_SHAPE_DISK ? HV3{ g1.x, g1.y, g1.z } : HV3{ g3.x, g3.y, g3.z };
+				const HV3 n = hnorm(nn);
+				const HV3 tmp = std::fabs(n.x) > 0.99f ? HV3{ 0, 1, 0 } : HV3{ 1, 0, 0 };
+				const HV3 t = hnorm(hcross(n, tmp)), sv = hnorm(hcross(t, n));
+				tabv.push_back(make_float4(n.x, n.y, n.z, 0)); tabv.push_back(make_float4(sv.x, sv.y, sv.z, 0)); tabv.push_back(make_float4(t.x, t.y, t.z, 0));
+			}
 		}
 		HIP_TRY(up(&c->d_shade_tab, tabv.data(), tabv.size() * sizeof(float4)));
 	}
@@ -1972,7 +1999,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	{
 		size_t tab = ((size_t)2 * s->n_lights + (size_t)4 * s->n_materials) * sizeof(float4) + (size_t)s->n_materials * sizeof(int) + 16;
 		c->tables_in_lds = tab <= 16 * 1024;
-		c->shade_lds_bytes = c->tables_in_lds ? tab + (c->scene_in_lds ? n4prims * sizeof(float4) + nmeta * sizeof(int4) : 0) : 0;
+		c->shade_lds_bytes = c->tables_in_lds ? tab + (c->scene_in_lds ? n4prims * sizeof(float4) + nmeta * sizeof(int4) + 3 * nmeta * sizeof(float4) : 0) : 0;
 		// k_shade's static LDS (tile index, keys, counters of the material sort) + tables + staging must stay within 64 KB a workgroup
 		const size_t shade_static = (size_t)JP_SHADE_TILE * 3 + (size_t)JP_SHADE_CLASSES * (JP_SHADE_TILE / JP_BLOCK) * (JP_BLOCK / 64) * 4 + 128;
 		const size_t stage_bytes = 16 + (size_t)std::max(1, planes) * 2 * JP_BLOCK * sizeof(float4);

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(REPO, "tests")); sys.path.insert(0, REPO)
 import harness as H
 jp = H.jp
 NAMES = ["table staging", "partition", "loop overhead", "wait: prefetched records + earlier stores", "decode, emission, closure, frame",
-         "next-event estimation", "BSDF sample + roulette", "output room + store issue", "closing barrier"]
+         "next-event estimation", "BSDF sample + roulette", "output room + store issue", "closing barrier", "memory wait at the end of the chunk"]
 spec = sys.argv[1].split(":")
 W, Hh = (int(x) for x in spec[1].split("x")) if len(spec) > 1 else (512, 512)
 spp = int(spec[2]) if len(spec) > 2 else 256
@@ -22,7 +22,7 @@ for lanes in ("1", "3"):
     buf = (ctypes.c_ulonglong * 16)(); assert lib.jp_dbg_shade_timing(buf) == 0
     ctx.render(p)
     assert lib.jp_dbg_shade_timing(buf) == 0
-    t = np.array(buf[:9], dtype=np.float64); waves = buf[9]
+    t = np.array(buf[:10], dtype=np.float64); waves = buf[15]
     print("%s %dx%dx%d, %s lane(s): %d k_shade waves, %.0f cycles per wave" % (spec[0], W, Hh, spp, lanes, waves, t.sum() / max(1, waves)))
     for n_, v in zip(NAMES, t):
         print("   %-44s %5.1f %%" % (n_, 100 * v / t.sum()))
