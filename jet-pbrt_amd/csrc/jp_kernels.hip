@@ -373,12 +373,12 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 	float4* s_stage = s_dyn + n_tab_all + threadIdx.x;
 	const unsigned int b = blockIdx.x, n = q.blk_q[cur][b];
 	const int nxt = cur ^ 1;
-	if (n == 0) { if (threadIdx.x == 0) { q.blk_q[nxt][b] = 0; q.blk_sh[b] = 0; } return; }
 #ifdef JP_SHADE_TIMING
 	unsigned long long t_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, t_last = __builtin_amdgcn_s_memtime();
 #endif
 	if (kTab)
-	{   // one array, one sweep, two loads in flight per thread: a single round trip to memory as a rule (five dependent copy loops
+	{   // (before the test of n: the table loads and the load of n are in flight together)
+		// one array, one sweep, two loads in flight per thread: a single round trip to memory as a rule (five dependent copy loops
 		// over five arrays were 13 % of a wave's lifetime on the Cornell box)
 		for (int i = threadIdx.x; i < n_tab_all; i += 2 * JP_BLOCK)
 		{
@@ -387,6 +387,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 			s_dyn[i] = a; if (two) s_dyn[i + JP_BLOCK] = c2;
 		}
 	}
+	if (n == 0) { if (threadIdx.x == 0) { q.blk_q[nxt][b] = 0; q.blk_sh[b] = 0; } return; }
 	if (threadIdx.x == 0) { s_ctr[0] = 0; s_ctr[1] = 0; s_ctr[2] = 0; }
 	__syncthreads();
 	const float4* lights = kTab ? (const float4*)s_lights : sc.lights;
@@ -407,17 +408,17 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 		const unsigned int plane = tid & 63u, wave = tid >> 6, npass = (count + JP_BLOCK - 1) / JP_BLOCK;
 		const unsigned long long ltm = (1ull << plane) - 1ull;
 		#pragma unroll 1
-		for (unsigned int r0 = 0; r0 < npass; r0 += 4)
+		for (unsigned int r0 = 0; r0 < npass; r0 += 8)
 		{
-			int pi[4];
+			int pi[8];                                                   // eight hit records in flight per thread
 			#pragma unroll
-			for (int u = 0; u < 4; u++)
+			for (int u = 0; u < 8; u++)
 			{
 				const unsigned int j = (r0 + u) * JP_BLOCK + tid;
 				pi[u] = j < count ? __float_as_int(q.hit[rbase + t0 + j].y) : -2;
 			}
 			#pragma unroll
-			for (int u = 0; u < 4; u++)
+			for (int u = 0; u < 8; u++)
 			{
 				const unsigned int r = r0 + u;
 				if (r >= npass) break;
@@ -428,13 +429,15 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 					key = m >= 0 ? 1u + (unsigned int)mat_type[m] : 0u;
 				}
 				s_key[r * JP_BLOCK + tid] = (unsigned char)key;
+				unsigned int mine = 0;                                   // lane c keeps the wave's count of class c: one LDS write per pass
 				#pragma unroll
 				for (int c = 0; c < JP_SHADE_CLASSES; c++)
 				{
 					unsigned int nc = 0;
 					if ((rc.class_mask >> c) & 1) nc = (unsigned int)__popcll(__ballot(key == (unsigned int)c));
-					if (plane == 0) s_cnt[c * seg + r * kWaves + wave] = nc;
+					if (plane == (unsigned int)c) mine = nc;
 				}
+				if (plane < JP_SHADE_CLASSES) s_cnt[plane * seg + r * kWaves + wave] = mine;
 			}
 		}
 		__syncthreads();
