@@ -428,6 +428,17 @@ __device__ __forceinline__ int traverse_wide(const uint4* __restrict__ wide, Pri
 // its own stage of its own ray, advance together and a finished lane can take the next ray while the others go on.  The order in
 // which a ray's nodes and primitives are visited, the arithmetic and the acceptance rules are those of the loops above: identical
 // hit records.  `stack` is the thread's column of the LDS stack.  done: the ray is finished (hit >= 0: accepted primitive).
+// Traversal stack of the resumable walkers (lane refill kernels): the first `cap` words of a thread's column live in LDS (word w of
+// thread t at lds[w * JP_BLOCK]), deeper ones in a global spill array (word w at spill[(w - cap) * stride]).  A stack as deep as the
+// tree is high is what the worst case needs and what almost no ray uses; keeping only the shallow part in LDS lets 8 workgroups
+// instead of 5-6 share a CU.
+struct WalkStack
+{
+	int* lds; int* spill; int cap; unsigned int stride;
+	__device__ __forceinline__ void put(int at, int v) const { if (at < cap) lds[at * JP_BLOCK] = v; else spill[(size_t)(at - cap) * stride] = v; }
+	__device__ __forceinline__ int get(int at) const { return at < cap ? lds[at * JP_BLOCK] : spill[(size_t)(at - cap) * stride]; }
+};
+
 template <int kMode> struct Walker;
 
 template <> struct Walker<0>
@@ -436,7 +447,7 @@ template <> struct Walker<0>
 	__device__ __forceinline__ void start(V3 o_, V3 d_, float tmin_, float tmax_)
 	{ o = o_; d = d_; ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z; tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; done = false; }
 	__device__ __forceinline__ bool heavy() const { return cur < 0; }                 // next step is a leaf (primitive tests), not a node
-	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, int* stack)
+	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, const WalkStack& stack)
 	{
 		if (cur >= 0)
 		{
@@ -458,11 +469,11 @@ template <> struct Walker<0>
 			{
 				const bool leftFirst = kAnyHit ? true : (ln <= rn);
 				cur = leftFirst ? cl : cr;
-				stack[sp * JP_BLOCK] = leftFirst ? cr : cl; sp++;
+				stack.put(sp, leftFirst ? cr : cl); sp++;
 			}
 			else if (hl) cur = cl;
 			else if (hr) cur = cr;
-			else if (sp > 0) { sp--; cur = stack[sp * JP_BLOCK]; }
+			else if (sp > 0) { sp--; cur = stack.get(sp); }
 			else done = true;
 		}
 		else
@@ -470,7 +481,7 @@ template <> struct Walker<0>
 			const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
 			for (int k = 0; k < count; k++)
 				if (prim_hit<4>(sc.prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) { done = true; return; } }
-			if (sp > 0) { sp--; cur = stack[sp * JP_BLOCK]; } else done = true;
+			if (sp > 0) { sp--; cur = stack.get(sp); } else done = true;
 		}
 	}
 };
@@ -481,7 +492,7 @@ template <> struct Walker<5>
 	__device__ __forceinline__ void start(V3 o_, V3 d_, float tmin_, float tmax_)
 	{ o = o_; d = d_; rd = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; lcount = 0; lk = 0; lfirst = 0; done = false; }
 	__device__ __forceinline__ bool heavy() const { return lcount > 0; }             // next step tests an object of the leaf just entered
-	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, int* stack)
+	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, const WalkStack& stack)
 	{   // traverse_ref: the node's own box, then left, then right; every object of a leaf in order
 		if (lcount > 0)
 		{
@@ -495,11 +506,11 @@ template <> struct Walker<5>
 			const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
 			const bool ok = ref_box(n0, n1, o, d, rd, tmin, tmax);
 			const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-			if (ok && left >= 0) { stack[sp * JP_BLOCK] = right; sp++; cur = left; return; }
+			if (ok && left >= 0) { stack.put(sp, right); sp++; cur = left; return; }
 			if (ok && right > 0) { lfirst = -left - 1; lcount = right; lk = 0; return; }
 		}
 		if (sp == 0) { done = true; return; }
-		sp--; cur = stack[sp * JP_BLOCK];
+		sp--; cur = stack.get(sp);
 	}
 };
 
@@ -513,9 +524,8 @@ template <> struct Walker<3>
 		ngx = 0; ngy = 0x80000000u; tgx = tgy = 0; sp = 0; hit = -1; done = false;       // the root: group base 0, one pending inner hit
 	}
 	__device__ __forceinline__ bool heavy() const { return tgy == 0u && ngy > 0x00ffffffu; }   // next step decodes a wide node (8 boxes), not a primitive / pop
-	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, int* stack_)
+	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, const WalkStack& stack)
 	{
-		unsigned int* stack = (unsigned int*)stack_;
 		if (tgy)
 		{   // one primitive
 			const int j = __ffs((int)tgy) - 1;
@@ -527,7 +537,7 @@ template <> struct Walker<3>
 			const uint4* __restrict__ wide = sc.wide;
 			const unsigned int bit = 31u - (unsigned int)__clz((int)ngy);
 			ngy &= ~(1u << bit);
-			if (ngy > 0x00ffffffu) { stack[(2 * sp) * JP_BLOCK] = ngx; stack[(2 * sp + 1) * JP_BLOCK] = ngy; sp++; }
+			if (ngy > 0x00ffffffu) { stack.put(2 * sp, (int)ngx); stack.put(2 * sp + 1, (int)ngy); sp++; }
 			const unsigned int slot = (bit - 24u) ^ octinv;
 			const unsigned int rel = (unsigned int)__popc(ngy & 0xffu & ~(0xffffffffu << slot));
 			const unsigned int idx = ngx + rel;
@@ -557,7 +567,7 @@ template <> struct Walker<3>
 			ngx = q1.x; ngy = (hm & 0xff000000u) | (q0.w >> 24);
 			tgx = q1.y; tgy = hm & 0x00ffffffu;
 		}
-		else if (sp > 0) { sp--; ngx = stack[(2 * sp) * JP_BLOCK]; ngy = stack[(2 * sp + 1) * JP_BLOCK]; }
+		else if (sp > 0) { sp--; ngx = (unsigned int)stack.get(2 * sp); ngy = (unsigned int)stack.get(2 * sp + 1); }
 		else done = true;
 	}
 };

@@ -866,13 +866,13 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_sort(SceneView sc, Queues q
 //     k * E + e) and a ray's verdict is one bit in an LDS bitmap; after a block barrier every thread adds, for the entries it owns,
 //     the visible contributions to the path's radiance in light order (integrator.cc:367-370) -- the reference's sum, run-to-run
 //     deterministic -- and only those contributions are read from HBM.
-// LDS: [stack: stack_words words][k_shadow_persist: bitmap of ceil(R * n_planes / 32) words]
+// LDS: [stack: stack_cap words per thread, deeper entries in the global spill array (WalkStack)][k_shadow_persist: bitmap of ceil(R * n_planes / 32) words]
 // ---------------------------------------------------------------------------------------------------------------------
 template <int kMode, int kRefill, bool kVote>
-__global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queues q, int cur_q, DevCounters* cnt)
+__global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queues q, int cur_q, int stack_cap, int* spill, DevCounters* cnt)
 {
 	__shared__ unsigned int s_next;
-	int* stack = (int*)s_dyn + threadIdx.x;
+	const WalkStack stack = { (int*)s_dyn + threadIdx.x, spill + blockIdx.x * JP_BLOCK + threadIdx.x, stack_cap, gridDim.x * JP_BLOCK };
 	const unsigned int b = blockIdx.x, n = q.blk_q[cur_q][b], rbase = b * q.R;
 	if (b == 0 && threadIdx.x == 0) { cnt->closest += cnt->n_queue[cur_q]; cnt->n_queue[cur_q ^ 1] = 0; cnt->n_shadow = 0; }
 	if (threadIdx.x == 0) s_next = 0;
@@ -919,11 +919,11 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queue
 }
 
 template <int kMode, int kRefill, bool kVote>
-__global__ void __launch_bounds__(JP_BLOCK) k_shadow_persist(SceneView sc, Queues q, RenderConst rc, int stack_words, DevCounters* cnt)
+__global__ void __launch_bounds__(JP_BLOCK) k_shadow_persist(SceneView sc, Queues q, RenderConst rc, int stack_cap, int* spill, DevCounters* cnt)
 {
 	__shared__ unsigned int s_next;
-	int* stack = (int*)s_dyn + threadIdx.x;
-	unsigned int* s_occ = (unsigned int*)s_dyn + stack_words;        // bit r set: ray r is occluded
+	const WalkStack stack = { (int*)s_dyn + threadIdx.x, spill + blockIdx.x * JP_BLOCK + threadIdx.x, stack_cap, gridDim.x * JP_BLOCK };
+	unsigned int* s_occ = (unsigned int*)s_dyn + stack_cap * JP_BLOCK;   // bit r set: ray r is occluded
 	const unsigned int b = blockIdx.x, E = q.blk_sh[b], rbase = b * q.R;
 	const unsigned int NP = (unsigned int)rc.n_planes, total = E * NP;
 	for (unsigned int i = threadIdx.x; i < (total + 31) / 32; i += JP_BLOCK) s_occ[i] = 0;
@@ -1368,6 +1368,10 @@ struct JpContext
 	Queues q; unsigned int cap = 0; int planes_alloc = 0; unsigned int blk_alloc = 0; int blocks_per_cu = 16;
 	std::vector<void*> qbufs;
 	float4* d_pix_acc = nullptr; size_t pix_acc_n = 0;
+	// lane refill kernels: traversal-stack words per thread kept in LDS, the rest spills to global memory (WalkStack).  Measured on the
+	// 280k-triangle scene (tree height 24): 8 / 12 / 16 words 1922 / 1926 / 1922 Msamples/s, 20 words or the whole stack 1634 / 1692.
+	int stack_lds_words = 12;
+	int* d_spill = nullptr; size_t spill_words = 0;
 	float* d_film = nullptr; size_t film_n = 0;
 	float* d_gamma = nullptr; unsigned char* d_rgb8 = nullptr; size_t rgb8_n = 0; unsigned char* h_rgb8 = nullptr; size_t h_rgb8_n = 0;   // jp_render_rgb8
 	float* h_film = nullptr; size_t h_film_n = 0;                // pinned staging buffer of jp_render (a pageable copy of the film costs ~2 ms)
@@ -1498,6 +1502,7 @@ int jp_destroy_context(JpContext* c)
 	if (!c->is_lane) free_scene(c);
 	free_queues(c);
 	if (c->d_pix_acc) hipFree(c->d_pix_acc);
+	if (c->d_spill) hipFree(c->d_spill);
 	if (c->d_film) hipFree(c->d_film);
 	if (c->h_film) hipHostFree(c->h_film);
 	if (c->d_gamma) hipFree(c->d_gamma);
@@ -2013,6 +2018,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	{   // material sort in k_shade: pays when the primitives carry more than one material kind (JETPBRT_SHADE_SORT = 0 / 1 forces it)
 		bool kinds[8] = { false, false, false, false, false, false, false, false }; int nk = 0;
 		for (int i = 0; i < s->n_primitives; i++) { const int m = s->prim_material[i]; const int k = m < 0 ? 7 : s->mat_type[m]; if (!kinds[k]) { kinds[k] = true; nk++; } }
+		if (const char* e = getenv("JETPBRT_STACK_LDS")) { const int v = atoi(e); if (v >= 2) c->stack_lds_words = v & ~1; }   // even: the wide tree's entries are word pairs
 		// lane refill in the traversal kernels (k_extend_persist / k_shadow_persist): on by default for scenes walked through global
 		// memory (measured on the 280k-triangle scene: k_extend 39.1 -> 28.4 ms, k_shadow 28.8 -> 18.9 ms per 128 spp; reference-tree
 		// mode 154 -> 227 Msamples/s); the LDS-resident Cornell box loses with it (reference-tree mode 1109 -> 965), so small scenes keep
@@ -2123,6 +2129,11 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 		const unsigned int cap = G * R;
 		int st = ensure_queues(c, cap, c->n_planes, G); if (st != JP_OK) return st;
 		c->q.cap = cap; c->q.R = R;
+		{   // spill area of the walkers' stacks: the words a thread may need beyond the ones kept in LDS
+			const int deep = std::max(c->stack_depth, c->trav_mode == 3 ? (int)(c->lds_bytes_shadow / (JP_BLOCK * sizeof(int))) : 0);
+			const size_t need = c->persist && deep > c->stack_lds_words ? (size_t)(deep - c->stack_lds_words) * G * JP_BLOCK : 1;
+			if (c->spill_words < need) { if (c->d_spill) hipFree(c->d_spill); c->d_spill = nullptr; HIP_TRY(hipMalloc((void**)&c->d_spill, need * sizeof(int))); c->spill_words = need; }
+		}
 		if (c->pix_acc_n < (size_t)npix) { if (c->d_pix_acc) hipFree(c->d_pix_acc); c->d_pix_acc = nullptr; HIP_TRY(hipMalloc((void**)&c->d_pix_acc, (size_t)npix * 16)); c->pix_acc_n = (size_t)npix; }
 
 		RenderConst rc; rc.width = rp->width; rc.height = rp->height; rc.spp = rp->spp; rc.max_depth = rp->max_depth; rc.seed = rp->seed;
@@ -2162,7 +2173,8 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 					Stamper t(c, CLS_EXTEND);
 					if (c->persist && (c->trav_mode == 0 || c->trav_mode == 3 || c->trav_mode == 5))
 					{
-						#define JP_LAUNCH_EP(M, R) do { if (c->vote) hipLaunchKernelGGL((k_extend_persist<M, R, true>), dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->d_cnt); else hipLaunchKernelGGL((k_extend_persist<M, R, false>), dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->d_cnt); } while (0)
+						const int ecap = std::min(c->stack_depth, c->stack_lds_words); const size_t elds = (size_t)ecap * JP_BLOCK * sizeof(int);
+						#define JP_LAUNCH_EP(M, R) do { if (c->vote) hipLaunchKernelGGL((k_extend_persist<M, R, true>), dim3(grid), dim3(JP_BLOCK), elds, c->stream, c->sv, c->q, cur, ecap, c->d_spill, c->d_cnt); else hipLaunchKernelGGL((k_extend_persist<M, R, false>), dim3(grid), dim3(JP_BLOCK), elds, c->stream, c->sv, c->q, cur, ecap, c->d_spill, c->d_cnt); } while (0)
 						if (c->trav_mode == 5) { if (c->persist >= 32) JP_LAUNCH_EP(5, 32); else if (c->persist >= 16) JP_LAUNCH_EP(5, 16); else JP_LAUNCH_EP(5, 8); }
 						else { if (c->persist >= 32) JP_LAUNCH_EP(0, 32); else if (c->persist >= 16) JP_LAUNCH_EP(0, 16); else JP_LAUNCH_EP(0, 8); }
 						#undef JP_LAUNCH_EP
@@ -2191,11 +2203,11 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 				{
 					Stamper t(c, CLS_SHADOW);
 					const size_t slds = c->trav_mode == 3 ? c->lds_bytes_shadow : lds;
-					const size_t plds = slds + (((size_t)c->q.R * c->n_planes + 31) / 32) * 4;
+					const int scap = std::min((int)(slds / (JP_BLOCK * sizeof(int))), c->stack_lds_words);     // stack words per thread kept in LDS
+					const size_t plds = (size_t)scap * JP_BLOCK * sizeof(int) + (((size_t)c->q.R * c->n_planes + 31) / 32) * 4;
 					if (c->persist && (c->trav_mode == 0 || c->trav_mode == 3 || c->trav_mode == 5) && plds <= 64 * 1024)
 					{
-						const int sw = (int)(slds / sizeof(int));
-						#define JP_LAUNCH_SP(M, R) do { if (c->vote) hipLaunchKernelGGL((k_shadow_persist<M, R, true>), dim3(grid), dim3(JP_BLOCK), plds, c->stream, c->sv, c->q, rc, sw, c->d_cnt); else hipLaunchKernelGGL((k_shadow_persist<M, R, false>), dim3(grid), dim3(JP_BLOCK), plds, c->stream, c->sv, c->q, rc, sw, c->d_cnt); } while (0)
+						#define JP_LAUNCH_SP(M, R) do { if (c->vote) hipLaunchKernelGGL((k_shadow_persist<M, R, true>), dim3(grid), dim3(JP_BLOCK), plds, c->stream, c->sv, c->q, rc, scap, c->d_spill, c->d_cnt); else hipLaunchKernelGGL((k_shadow_persist<M, R, false>), dim3(grid), dim3(JP_BLOCK), plds, c->stream, c->sv, c->q, rc, scap, c->d_spill, c->d_cnt); } while (0)
 						if (c->trav_mode == 5) { if (c->persist >= 32) JP_LAUNCH_SP(5, 32); else if (c->persist >= 16) JP_LAUNCH_SP(5, 16); else JP_LAUNCH_SP(5, 8); }
 						else if (c->trav_mode == 3) { if (c->persist >= 32) JP_LAUNCH_SP(3, 32); else if (c->persist >= 16) JP_LAUNCH_SP(3, 16); else JP_LAUNCH_SP(3, 8); }
 						else { if (c->persist >= 32) JP_LAUNCH_SP(0, 32); else if (c->persist >= 16) JP_LAUNCH_SP(0, 16); else JP_LAUNCH_SP(0, 8); }
@@ -2257,6 +2269,7 @@ void sync_lane_scene(JpContext* c, JpContext* l)
 {
 	l->have_scene = c->have_scene; l->sv = c->sv; l->stack_depth = c->stack_depth; l->scene_in_lds = c->scene_in_lds;
 	l->lds_bytes = c->lds_bytes; l->lds_bytes_shadow = c->lds_bytes_shadow; l->trav_mode = c->trav_mode; l->n_planes = c->n_planes;
+	l->stack_lds_words = c->stack_lds_words;
 	l->ray_sort = c->ray_sort; l->persist = c->persist; l->vote = c->vote; l->shade_sort = c->shade_sort; l->class_mask = c->class_mask;
 	l->has_null_material = c->has_null_material; l->tables_in_lds = c->tables_in_lds; l->stage_nee = c->stage_nee; l->shade_lds_bytes = c->shade_lds_bytes;
 	l->profiling = c->profiling;
