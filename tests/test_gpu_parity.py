@@ -962,7 +962,8 @@ def test_wavefront_sorts_and_lane_refill_do_not_change_the_film(H, gpu_ctx, monk
     """the round-2 scheduling changes only move work between lanes: material sort in k_shade on / off, ray sort in the traversal
     kernels, lane refill (k_extend_persist / k_shadow_persist) with every refill threshold and with / without the vote, on the binary
     tree (mode 0, forced), the 8-wide shadow tree and the reference tree, a scene with a null-material primitive (extra iterations),
-    tiny regions (one workgroup per 256 slots) and a region count that leaves most lanes without a ray -- all bit-identical"""
+    tiny regions (one workgroup per 256 slots) and a region count that leaves most lanes without a ray, traversal stacks that spill
+    to global memory after 2 or 4 words -- all bit-identical"""
     W, Hh, spp = 96, 64, 6
     hb, sp = _scene(H, name, W, Hh)
     p = H.jp.render_params(W, Hh, spp, 5, 77)
@@ -985,6 +986,8 @@ def test_wavefront_sorts_and_lane_refill_do_not_change_the_film(H, gpu_ctx, monk
     if mode != 2:                                                  # walked through global memory: the refill kernels apply
         variants += [{"JETPBRT_PERSIST": r, "JETPBRT_VOTE": v} for r in ("8", "16", "32") for v in ("0", "1")]
         variants += [{"JETPBRT_PERSIST": "16", "JETPBRT_BLOCKS_PER_CU": "64"}, {"JETPBRT_PERSIST": "16", "JETPBRT_MAX_SLOTS": str(W * Hh)}]
+        # traversal stacks: 2 / 4 words per thread in LDS, everything deeper through the global spill array (WalkStack); whole stack in LDS
+        variants += [{"JETPBRT_PERSIST": "16", "JETPBRT_STACK_LDS": w} for w in ("2", "4", "64")]
     for env in variants:
         film, c2, _ = render(env)
         assert np.array_equal(film.view(np.uint32), base.view(np.uint32)) and c2 == cnt, env
@@ -1001,3 +1004,5 @@ def test_wavefront_sorts_and_lane_refill_do_not_change_the_film(H, gpu_ctx, monk
     for r, v in (("8", "0"), ("16", "0"), ("16", "1"), ("32", "0")):
         r1, rc1, _ = render({"JETPBRT_PERSIST": r, "JETPBRT_VOTE": v}, rsp)
         assert rm == 5 and np.array_equal(r0.view(np.uint32), r1.view(np.uint32)) and rc0 == rc1, (r, v)
+    r2, rc2, _ = render({"JETPBRT_PERSIST": "16", "JETPBRT_STACK_LDS": "2"}, rsp)          # the reference tree's walker on a spilling stack
+    assert np.array_equal(r0.view(np.uint32), r2.view(np.uint32)) and rc0 == rc2
