@@ -1356,7 +1356,7 @@ struct JpContext
 	int n_cus = 256;
 	// scene
 	bool have_scene = false;
-	SceneView sv; int stack_depth = 1; bool scene_in_lds = false; size_t lds_bytes = 0, lds_bytes_shadow = 0;
+	SceneView sv; int stack_depth = 1; bool scene_in_lds = false, shade_prims_in_lds = false; size_t lds_bytes = 0, lds_bytes_shadow = 0;
 	void *d_flat = nullptr, *d_wide = nullptr, *d_cut = nullptr; bool ray_sort = false; int trav_mode = 0;
 	bool vote = false; int persist = 0;                                             // lane refill in the closest-hit traversal of large scenes (k_extend_persist): refill threshold, 0 = off
 	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr, *d_shade_tab = nullptr;
@@ -2007,9 +2007,12 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	{
 		size_t tab = ((size_t)2 * s->n_lights + (size_t)4 * s->n_materials) * sizeof(float4) + (size_t)s->n_materials * sizeof(int) + 16;
 		c->tables_in_lds = tab <= 16 * 1024;
-		c->shade_lds_bytes = c->tables_in_lds ? tab + (c->scene_in_lds ? n4prims * sizeof(float4) + nmeta * sizeof(int4) + 3 * nmeta * sizeof(float4) : 0) : 0;
-		// k_shade's static LDS (tile index, keys, counters of the material sort) + tables + staging must stay within 64 KB a workgroup
+		// k_shade's static LDS (tile index, keys, counters of the material sort) + tables + staging must stay within 64 KB a workgroup;
+		// beyond 24 KB of tables the kernel's three workgroups per CU would not fit the CU's LDS either
 		const size_t shade_static = (size_t)JP_SHADE_TILE * 3 + (size_t)JP_SHADE_CLASSES * (JP_SHADE_TILE / JP_BLOCK) * (JP_BLOCK / 64) * 4 + 128;
+		const size_t prim_part = n4prims * sizeof(float4) + nmeta * sizeof(int4) + 3 * nmeta * sizeof(float4);     // records, meta, shading frames
+		c->shade_prims_in_lds = c->tables_in_lds && c->scene_in_lds && tab + prim_part <= 24 * 1024;
+		c->shade_lds_bytes = c->tables_in_lds ? tab + (c->shade_prims_in_lds ? prim_part : 0) : 0;
 		const size_t stage_bytes = 16 + (size_t)std::max(1, planes) * 2 * JP_BLOCK * sizeof(float4);
 		c->stage_nee = c->tables_in_lds && std::max(1, planes) <= 4 && shade_static + c->shade_lds_bytes + stage_bytes <= 64 * 1024;
 		if (c->stage_nee) c->shade_lds_bytes += stage_bytes;
@@ -2194,7 +2197,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 					const bool st = c->stage_nee;
 					#define JP_LAUNCH_SHADE(A, B, C) do { if (c->shade_sort) hipLaunchKernelGGL((k_shade<A, B, C, true>), dim3(grid), dim3(JP_BLOCK), c->shade_lds_bytes, c->stream, c->sv, c->q, rc, cur, c->d_cnt); \
 					                                   else hipLaunchKernelGGL((k_shade<A, B, C, false>), dim3(grid), dim3(JP_BLOCK), c->shade_lds_bytes, c->stream, c->sv, c->q, rc, cur, c->d_cnt); } while (0)
-					if (c->tables_in_lds && c->scene_in_lds) { if (st) JP_LAUNCH_SHADE(true, true, true); else JP_LAUNCH_SHADE(true, true, false); }
+					if (c->shade_prims_in_lds) { if (st) JP_LAUNCH_SHADE(true, true, true); else JP_LAUNCH_SHADE(true, true, false); }
 					else if (c->tables_in_lds) { if (st) JP_LAUNCH_SHADE(true, false, true); else JP_LAUNCH_SHADE(true, false, false); }
 					else JP_LAUNCH_SHADE(false, false, false);
 					#undef JP_LAUNCH_SHADE
@@ -2267,7 +2270,7 @@ int make_lanes(JpContext* c, int extra)
 // a lane walks the same device tables as its parent (it owns none of them)
 void sync_lane_scene(JpContext* c, JpContext* l)
 {
-	l->have_scene = c->have_scene; l->sv = c->sv; l->stack_depth = c->stack_depth; l->scene_in_lds = c->scene_in_lds;
+	l->have_scene = c->have_scene; l->sv = c->sv; l->stack_depth = c->stack_depth; l->scene_in_lds = c->scene_in_lds; l->shade_prims_in_lds = c->shade_prims_in_lds;
 	l->lds_bytes = c->lds_bytes; l->lds_bytes_shadow = c->lds_bytes_shadow; l->trav_mode = c->trav_mode; l->n_planes = c->n_planes;
 	l->stack_lds_words = c->stack_lds_words;
 	l->ray_sort = c->ray_sort; l->persist = c->persist; l->vote = c->vote; l->shade_sort = c->shade_sort; l->class_mask = c->class_mask;

@@ -286,11 +286,13 @@ def test_bunny_scene_full_bvh(H, gpu_ctx):
     assert abs(c.closest_rays - cnt.closest_rays) <= max(8, cnt.closest_rays * 2e-4)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
-def test_random_scenes(H, gpu_ctx, tmp_path, seed):
-    """random triangle soups, rectangles, spheres, every material, triangle / rectangle / sphere lights, env light"""
+@pytest.mark.parametrize("seed,n_tris", [(1, 400), (2, 400), (3, 400), (4, 400), (5, 250), (6, 150), (7, 90)])
+def test_random_scenes(H, gpu_ctx, tmp_path, seed, n_tris):
+    """random triangle soups, rectangles, spheres, every material, triangle / rectangle / sphere lights, env light; the sizes
+    cross the limits of the LDS-resident variants (hierarchy in LDS below ~300 primitives, k_shade's primitive + frame tables
+    below ~190, the flat leaf list at 64)"""
     W, Hh, spp = 96, 80, 8
-    hb = H.build_random_scene(H.scenes.HostBackend("r"), W, Hh, seed, n_tris=400, tmpdir=str(tmp_path))
+    hb = H.build_random_scene(H.scenes.HostBackend("r"), W, Hh, seed, n_tris=n_tris, tmpdir=str(tmp_path))
     sp = hb.flatten()
     gpu_ctx.upload(sp)
     p = H.jp.render_params(W, Hh, spp, 5, 5 + seed)
