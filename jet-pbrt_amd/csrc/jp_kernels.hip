@@ -240,6 +240,23 @@ extern __shared__ float4 s_dyn[];      // 16-byte aligned base
 // kMode 2: tiny scene: flat leaf list (uniform loads from global), primitives in LDS, no stack
 // kMode 3: large scene: 8-wide quantised BVH in global memory, (group, hits) stack pairs in LDS
 // kMode 5: reference semantics: the caller's tree node for node, unordered, the reference's box test (traverse_ref)
+// -DJP_SHADE_TIMING (diagnostic builds only, tools/shade_timing.py): every wave of k_shade adds the shader-clock cycles it spends
+// in each section of the kernel to g_shade_t; jp_dbg_shade_timing reads and clears the sums.
+// -DJP_TRAV_TIMING: the same for k_extend<2> / k_shadow<2> (sections listed in tools/shade_timing.py).
+#if defined(JP_SHADE_TIMING) || defined(JP_TRAV_TIMING)
+__device__ unsigned long long g_shade_t[16];
+#define JP_TSX(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[i] += t_ - t_last; t_last = t_; } while (0)
+#endif
+#ifdef JP_SHADE_TIMING
+#define JP_TS(i) JP_TSX(i)
+#else
+#define JP_TS(i) do { } while (0)
+#endif
+#ifdef JP_TRAV_TIMING
+#define JP_TT(i) JP_TSX(i)
+#else
+#define JP_TT(i) do { } while (0)
+#endif
 template <int kMode>
 struct SceneAccess;
 template <> struct SceneAccess<0>
@@ -335,14 +352,6 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend(SceneView sc, Queues q, int
 // (measured on the reference's Cornell scene: k_shade 3124 -> wave64 instructions per 64 paths at lane utilisation 0.42 before).
 // The partition is stable, so the big class still reads its records almost in queue order.  Every path computes exactly what it
 // computed before; only the order inside this block's output regions changes.
-// -DJP_SHADE_TIMING (diagnostic builds only, tools/shade_timing.py): every wave of k_shade adds the shader-clock cycles it spends
-// in each section of the kernel to g_shade_t; jp_dbg_shade_timing reads and clears the sums.
-#ifdef JP_SHADE_TIMING
-__device__ unsigned long long g_shade_t[16];
-#define JP_TS(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[i] += t_ - t_last; t_last = t_; } while (0)
-#else
-#define JP_TS(i) do { } while (0)
-#endif
 #ifndef JP_SHADE_TILE
 #define JP_SHADE_TILE 8192
 #endif
@@ -738,8 +747,12 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 template <int kMode>
 __global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow(SceneView sc, Queues q, RenderConst rc, int depth, DevCounters* cnt)
 {
+#ifdef JP_TRAV_TIMING
+	unsigned long long t_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, t_last = __builtin_amdgcn_s_memtime();
+#endif
 	SceneAccess<kMode> acc(sc, depth);
 	const unsigned int b = blockIdx.x, E = q.blk_sh[b], rbase = b * q.R;
+	JP_TT(0);                                                      // [0] primitive records to LDS, region fill
 	unsigned int rays = 0, occ = 0;
 	// software prefetch: the next entry's header and first ray are requested before this entry is traced
 	float4 so_n = make_float4(0, 0, 0, 0), sd_n = make_float4(0, 0, 1, 0);
@@ -747,6 +760,11 @@ __global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow(SceneView sc, Queues q, 
 	for (unsigned int j = threadIdx.x; j < E; j += JP_BLOCK)
 	{
 		const unsigned int e = rbase + j;
+#ifdef JP_TRAV_TIMING
+		JP_TT(1);                                                  // [1] loop overhead
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		JP_TT(2);                                                  // [2] wait for the prefetched entry (and earlier stores)
+#endif
 		const float4 so = so_n; float4 sd = sd_n;
 		if (j + JP_BLOCK < E) { so_n = q.sh_o[e + JP_BLOCK]; sd_n = q.sh_d[e + JP_BLOCK]; }
 		const int packed = __float_as_int(so.w);
@@ -761,13 +779,32 @@ __global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow(SceneView sc, Queues q, 
 			float tmax = sd.w;
 			const V3 dir = xyz(sd);
 			if (k + 1 < n) sd = q.sh_d[(size_t)(k + 1) * q.cap + e];
+			JP_TT(3);                                              // [3] load issue
+#ifdef JP_TRAV_TIMING
+			int hit;
+			if constexpr (kMode == 2)
+			{
+				const unsigned int m = flat_boxes<false>(sc.flat, sc.n_flat, xyz(so), dir, 0.001f, tmax);
+				JP_TT(4);                                          // [4] box phase
+				hit = flat_prims<true, false, 5>(m, acc.prims, xyz(so), dir, 0.001f, tmax);
+				JP_TT(5);                                          // [5] primitive phase
+			}
+			else hit = acc.template trace<true>(sc, xyz(so), dir, 0.001f, tmax);
+#else
 			const int hit = acc.template trace<true>(sc, xyz(so), dir, 0.001f, tmax);
+#endif
 			rays++;
 			if (hit >= 0) occ++;
 			else { a = a + xyz(c4); any = true; }
+			JP_TT(6);                                              // [6] contribution (waits for its load)
 		}
 		if (any) q.lacc[slot] = make_float4(a.x, a.y, a.z, 0.f);
+		JP_TT(7);                                                  // [7] radiance store
 	}
+#ifdef JP_TRAV_TIMING
+	JP_TT(1);
+	if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 8; i++) atomicAdd(&g_shade_t[i], t_acc[i]); atomicAdd(&g_shade_t[15], 1ull); }
+#endif
 	for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); occ += __shfl_down(occ, off); }
 	if ((threadIdx.x & 63) == 0) { if (rays) atomicAdd(&cnt->shadow, (unsigned long long)rays); if (occ) atomicAdd(&cnt->shadow_occ, (unsigned long long)occ); }
 }
@@ -2496,7 +2533,7 @@ int jp_trace(JpContext* c, int32_t n, const float* origin, const float* dir, con
 
 } // extern "C"
 
-#ifdef JP_SHADE_TIMING
+#if defined(JP_SHADE_TIMING) || defined(JP_TRAV_TIMING)
 extern "C" int jp_dbg_shade_timing(unsigned long long* out16)
 {
 	unsigned long long z[16] = { 0 };

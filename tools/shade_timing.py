@@ -9,6 +9,10 @@ import harness as H
 jp = H.jp
 NAMES = ["table staging", "partition", "loop overhead", "wait: prefetched records + earlier stores", "decode, emission, closure, frame",
          "next-event estimation", "BSDF sample + roulette", "output room + store issue", "closing barrier", "memory wait at the end of the chunk"]
+TRAV = ["primitive records to LDS, region fill", "loop overhead", "wait: prefetched entry + earlier stores", "load issue (contribution, next ray)",
+        "box phase", "primitive phase", "contribution (waits for its load)", "radiance store", "-", "-"]
+if os.environ.get("JP_TIMING_KERNEL") == "shadow":                # a -DJP_TRAV_TIMING build: k_shadow<2> instead of k_shade
+    NAMES = TRAV
 spec = sys.argv[1].split(":")
 W, Hh = (int(x) for x in spec[1].split("x")) if len(spec) > 1 else (512, 512)
 spp = int(spec[2]) if len(spec) > 2 else 256
@@ -23,7 +27,7 @@ for lanes in ("1", "3"):
     ctx.render(p)
     assert lib.jp_dbg_shade_timing(buf) == 0
     t = np.array(buf[:10], dtype=np.float64); waves = buf[15]
-    print("%s %dx%dx%d, %s lane(s): %d k_shade waves, %.0f cycles per wave" % (spec[0], W, Hh, spp, lanes, waves, t.sum() / max(1, waves)))
+    print("%s %dx%dx%d, %s lane(s): %d timed waves, %.0f cycles per wave" % (spec[0], W, Hh, spp, lanes, waves, t.sum() / max(1, waves)))
     for n_, v in zip(NAMES, t):
         print("   %-44s %5.1f %%" % (n_, 100 * v / t.sum()))
     ctx.close()
