@@ -8,10 +8,11 @@
 //   k_extend   closest hit per queued ray: BVH traversal with an LDS stack, scene in LDS when it fits; tiny scenes use a
 //              flat wide node tested wave-uniformly
 //   k_shade    emission, material closure, NEE light samples -> shadow rays, BSDF sample, Russian roulette,
-//              surviving paths compacted (wave ballots + block prefix) into the next ray queue
+//              surviving paths compacted (wave ballots, room taken from an LDS counter per wave) into the next ray queue
 //   k_shadow   any-hit traversal per shadow entry, visible contributions added to the path's radiance in light order
 //   k_resolve  per pixel: sequential fp32 sum over the batch's samples in index order (integrator.cc:102-105)
-// Round 2: k_shade partitions its 1024-path tiles by material class first (tile_partition: wave ballots + block prefix);
+// Round 2: k_shade partitions its workgroup's region by material class first (wave ballots + one block scan of LDS counters) and
+// shades it in 64-path chunks the waves take from an LDS counter, expensive classes first, no barrier in between;
 // large scenes trace through k_extend_persist / k_shadow_persist (resumable Walker<mode> steps, idle lanes refilled from the
 // region, per-iteration vote); k_extend_sort / k_shadow_sort (opt-in) partition rays by expected work; k_tonemap8 delivers the
 // film as 8-bit gamma-encoded RGB; k_bsdf evaluates any BSDF class of bsdf.h by value (jp_xbsdf.h).
@@ -94,41 +95,6 @@ __device__ __forceinline__ void pixel_of(const RenderConst& rc, int pix, int& x,
 	if (rc.lane_count > 1) { const int m = r / rc.lane_rows; r = (rc.lane_index + m * rc.lane_count) * rc.lane_rows + (r - m * rc.lane_rows); }   // lane row -> shard row
 	const int j = r / rc.band_rows;
 	y = (rc.shard_index + j * rc.shard_count) * rc.band_rows + (r - j * rc.band_rows);
-}
-
-// block-wide exclusive prefix of a per-thread flag: wave ballot + popcount, per-wave totals through LDS.
-// Returns this thread's offset inside the block and the block total; every thread of the block must call it.
-__device__ __forceinline__ unsigned int block_prefix(bool flag, unsigned int* s_tmp /* [JP_BLOCK/64] */, unsigned int& total)
-{
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const unsigned long long m = __ballot(flag);
-	const unsigned int prefix = (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-	__syncthreads();                                         // s_tmp reuse guard
-	if (lane == 0) s_tmp[wave] = (unsigned int)__popcll(m);
-	__syncthreads();
-	unsigned int base = 0, tot = 0;
-	#pragma unroll
-	for (int w = 0; w < JP_BLOCK / 64; w++) { const unsigned int t = s_tmp[w]; if (w < wave) base += t; tot += t; }
-	total = tot;
-	return base + prefix;
-}
-
-// two flags at once (counts packed 16:16), ONE barrier: s_tmp2 is double-buffered by `phase`, so the next call's
-// writes cannot race with this call's reads.  Every thread of the block must call it.
-__device__ __forceinline__ void block_prefix2(bool fa, bool fb, unsigned int* s_tmp2 /* [2][JP_BLOCK/64] */, unsigned int phase,
-                                             unsigned int& pa, unsigned int& ta, unsigned int& pb, unsigned int& tb)
-{
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const unsigned long long lt = (1ull << lane) - 1ull;
-	const unsigned long long ma = __ballot(fa), mb = __ballot(fb);
-	unsigned int* t = s_tmp2 + (phase & 1u) * (JP_BLOCK / 64);
-	if (lane == 0) t[wave] = (unsigned int)__popcll(ma) | ((unsigned int)__popcll(mb) << 16);
-	__syncthreads();
-	unsigned int base = 0, tot = 0;
-	#pragma unroll
-	for (int w = 0; w < JP_BLOCK / 64; w++) { const unsigned int v = t[w]; if (w < wave) base += v; tot += v; }
-	pa = (base & 0xffffu) + (unsigned int)__popcll(ma & lt); ta = tot & 0xffffu;
-	pb = (base >> 16) + (unsigned int)__popcll(mb & lt); tb = tot >> 16;
 }
 
 // wave-level take from an LDS counter: lane 0 adds the wave-uniform n, every lane gets the old value.  All 64 lanes must be active.
@@ -345,9 +311,9 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend(SceneView sc, Queues q, int
 // light) are LDS reads instead of a chain of global loads.
 // kStage (<= 4 emitting lights): the NEE rays of a path are staged in LDS and a shadow entry is allocated only when at
 // least one ray survived the rejections of integrator.cc:362-367, so k_shadow never meets an empty entry.
-// kSort ("material sort"): the paths of a 1024-path tile are partitioned by the material class of the primitive they hit (none /
-// matte / mirror / glass / plastic / metal) before they are shaded, with wave ballots + a block prefix over LDS counters, and
-// the tile is then shaded in that order: a wave holds paths of ONE class except at class boundaries, so the microfacet code of
+// kSort ("material sort"): the paths of the workgroup's region (<= JP_SHADE_TILE) are partitioned by the material class of the
+// primitive they hit (none / matte / mirror / glass / plastic / metal) before they are shaded, with wave ballots + a block scan over
+// LDS counters, and the region is then shaded in that order, expensive classes first: a wave holds paths of ONE class except at class boundaries, so the microfacet code of
 // bsdf.cc / microfacet.cc runs with full waves on the paths that need it instead of with 10-15 % of the lanes in every wave
 // (measured on the reference's Cornell scene: k_shade 3124 -> wave64 instructions per 64 paths at lane utilisation 0.42 before).
 // The partition is stable, so the big class still reads its records almost in queue order.  Every path computes exactly what it
