@@ -48,7 +48,7 @@ struct Queues
 	float4 *ray_o[2], *ray_d[2], *beta[2];     // ping-pong ray queues: (o, slot) (d, flags) (beta, key)
 	float2 *hit;                               // (t, device prim index or -1) per queued ray
 	float4 *lacc;                              // per slot: radiance of the path so far
-	float4 *sh_o;                              // per shadow entry: (origin, slot | count << 24)
+	float4 *sh_o;                              // per shadow entry: (origin, slot | count << RenderConst::slot_bits)
 	float4 *sh_d, *sh_c;                       // plane k at [k * cap + q]: (dir, tmax), (contribution, visible flag)
 	unsigned int *blk_q[2], *blk_sh;           // per-block fill of the regions
 	unsigned int cap;                          // G * R entries per queue array
@@ -65,6 +65,7 @@ struct RenderConst
 	int s0, sbatch;      // first sample index and sample count of this batch
 	int n_planes;        // shadow ray planes (lights that can emit)
 	int tiled;           // pixel enumeration: 16 x 4 tiles (1) or row-major (0)
+	int slot_bits;       // a shadow entry's header word: slot in the low slot_bits bits, ray count above (27 + 5, or 24 + 8 for scenes with more than 31 emitting lights)
 	int sampler_debug;   // JP_SAMPLER_DEBUG: every draw is 0.5
 	int class_mask;      // material classes present in the scene (bit 0: none / null material, bit 1 + JP_MAT_*), k_shade<kSort>
 	int lane_index, lane_count, lane_rows;   // stream lanes: this launch owns the lane_rows-row groups g of the shard's rows with g % lane_count == lane_index
@@ -615,7 +616,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 						k++;
 					}
 				}
-				if (!kStage) q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
+				if (!kStage) q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << rc.slot_bits)));
 			}
 		}
 		JP_TS(5);                                                 // [5] next-event estimation
@@ -668,7 +669,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 			}
 			if (k > 0)
 			{
-				q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << 24)));
+				q.sh_o[qs] = make_float4(p.x, p.y, p.z, __int_as_float(slot | (k << rc.slot_bits)));
 				for (int kk = 0; kk < k; kk++)
 				{
 					q.sh_d[(size_t)kk * q.cap + qs] = s_stage[(2 * kk) * JP_BLOCK];
@@ -734,7 +735,7 @@ __global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow(SceneView sc, Queues q, 
 		const float4 so = so_n; float4 sd = sd_n;
 		if (j + JP_BLOCK < E) { so_n = q.sh_o[e + JP_BLOCK]; sd_n = q.sh_d[e + JP_BLOCK]; }
 		const int packed = __float_as_int(so.w);
-		const int slot = packed & 0xffffff, n = (packed >> 24) & 0xff;
+		const int slot = packed & ((1 << rc.slot_bits) - 1), n = (int)((unsigned int)packed >> rc.slot_bits);
 		if (n == 0) continue;
 		bool any = false;
 		const float4 L = q.lacc[slot];                               // issued up front: its latency hides behind the traversal
@@ -957,7 +958,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shadow_persist(SceneView sc, Queue
 				{
 					const unsigned int k = my / E, e = my - k * E;
 					const float4 so = q.sh_o[rbase + e];
-					if (k < (((unsigned int)__float_as_int(so.w) >> 24) & 0xffu))
+					if (k < ((unsigned int)__float_as_int(so.w) >> rc.slot_bits))
 					{
 						const float4 sd = q.sh_d[(size_t)k * q.cap + rbase + e];
 						w.start(xyz(so), xyz(sd), 0.001f, sd.w);     // FScene::Occluded scene.h:36-47
@@ -980,7 +981,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shadow_persist(SceneView sc, Queue
 	for (unsigned int e = threadIdx.x; e < E; e += JP_BLOCK)
 	{
 		const int packed = __float_as_int(q.sh_o[rbase + e].w);
-		const int slot = packed & 0xffffff; const unsigned int nr = ((unsigned int)packed >> 24) & 0xffu;
+		const int slot = packed & ((1 << rc.slot_bits) - 1); const unsigned int nr = (unsigned int)packed >> rc.slot_bits;
 		unsigned int vm = 0;
 		for (unsigned int k = 0; k < nr; k++) { const unsigned int r = k * E + e; if (!((s_occ[r >> 5] >> (r & 31u)) & 1u)) vm |= 1u << k; }
 		rays += nr; occ += nr - (unsigned int)__popc(vm);
@@ -1024,7 +1025,7 @@ __global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow_sort(SceneView sc, Queue
 			if (j < count)
 			{
 				const float4 so = q.sh_o[rbase + e0 + j];
-				const int nr = (__float_as_int(so.w) >> 24) & 0xff;
+				const int nr = (int)((unsigned int)__float_as_int(so.w) >> rc.slot_bits);
 				int pc = 0;
 				for (int k = 0; k < nr; k++)
 				{
@@ -1057,7 +1058,7 @@ __global__ void __launch_bounds__(JP_BLOCK, 4) k_shadow_sort(SceneView sc, Queue
 			if (tk < nch && c0 + lane < count) { jn = s_idx[c0 + lane]; so_n = q.sh_o[rbase + e0 + jn]; sd_n = q.sh_d[rbase + e0 + jn]; }
 			if (pos >= count) continue;
 			const int packed = __float_as_int(so.w);
-			const int slot = packed & 0xffffff, nr = (packed >> 24) & 0xff;
+			const int slot = packed & ((1 << rc.slot_bits) - 1), nr = (int)((unsigned int)packed >> rc.slot_bits);
 			if (nr == 0) continue;
 			bool any = false;
 			const float4 L = q.lacc[slot];                               // issued up front: its latency hides behind the traversal
@@ -2113,7 +2114,11 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 	if (npix > 0)
 	{
 		if (npix > (1 << 24)) return fail(JP_ERR_UNSUPPORTED, "jp_render: more than 2^24 pixels per shard");
-		const unsigned int PMAX = 1u << 24;                          // slot index is packed in 24 bits
+		// a shadow entry's header packs (slot, ray count) in 32 bits: 27 + 5 as a rule; batches of up to 2^26 slots (regions of <= 8192
+		// slots: up to 8192 workgroups a launch, whose tail -- the last workgroups finishing on an emptying GPU -- weighs a quarter of
+		// what it does with 2^24)
+		const int slot_bits = c->n_planes <= 31 ? 27 : 24;
+		const unsigned int PMAX = slot_bits == 27 ? (1u << 26) : (1u << 24);
 		// memory budget for the queues: ~ (120 + 32 * planes) bytes per slot
 		size_t freeB = 0, totalB = 0; hipMemGetInfo(&freeB, &totalB);
 		size_t per = 136 + 32 * (size_t)c->n_planes;
@@ -2147,6 +2152,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 		rc.lane_index = lane_index; rc.lane_count = lane_count; rc.lane_rows = lane_group; rc.class_mask = c->class_mask; rc.sampler_debug = rp->sampler_mode == JP_SAMPLER_DEBUG ? 1 : 0;
 		// measured: +6 % on the 280k-triangle scene (cache reuse), -8 % on the LDS-resident Cornell box (coherent waves finish
 		// together or not at all, which unbalances the workgroups) -> tiles only when traversal goes through global memory
+		rc.slot_bits = slot_bits;
 		rc.tiled = (c->trav_mode == 0 && rp->width % 16 == 0 && local_rows % 4 == 0 && !getenv("JETPBRT_NO_TILES")) ? 1 : 0;
 		const int grid = (int)G;
 		const size_t lds = c->lds_bytes;

@@ -158,6 +158,25 @@ def test_edge_cases(H, gpu_ctx):
     assert not np.array_equal(a, c) and abs(a.mean() - c.mean()) < 0.02
 
 
+def test_more_than_31_lights(H, gpu_ctx):
+    """a shadow entry's header packs (slot, ray count): 27 + 5 bits as a rule, 24 + 8 for scenes with more than 31 emitting lights
+    (smaller batches); 40 point lights + the Cornell box's own lights against the oracle"""
+    W, Hh, spp = 40, 32, 4
+
+    def extras(b, m):
+        for i in range(40):
+            b.pointlight((60.0 + 11.0 * i, 200.0 + 7.0 * (i % 5), -100.0 - 9.0 * (i % 7)), (900.0 + 40.0 * i, 800.0, 700.0 - 10.0 * i))
+    hb = H.scenes.build_cornell(H.scenes.HostBackend("many"), W, Hh, lambert_only=False, extras=extras, env=(0.01, 0.01, 0.02))
+    sp = hb.flatten()
+    gpu_ctx.upload(sp)
+    p = H.jp.render_params(W, Hh, spp, 5, 3)
+    film = gpu_ctx.render(p)
+    ref, cnt = H.oracle_render(sp, p, 4)
+    c = gpu_ctx.counters()
+    assert c.shadow_rays == cnt.shadow_rays and c.closest_rays == cnt.closest_rays
+    assert_film(gpu_ctx, film, ref, "cornell")
+
+
 def test_band_shards_union_is_the_full_film_bit_exact(H, gpu_ctx):
     """multi-GPU contract on one GPU: shard films are zero outside their bands and sum to the unsharded film"""
     W, Hh, spp = 72, 90, 6
