@@ -32,6 +32,7 @@ inline float area(const B& b)
 struct Builder
 {
 	const std::vector<B>& pb; std::vector<float>& cen; std::vector<int32_t>& idx; FlatBVH& out; int maxLeaf;
+	float travCost = 1.0f;                                       // cost of a node visit in primitive tests (JETPBRT_SAH_TRAV_COST)
 	Builder(const std::vector<B>& pb, std::vector<float>& cen, std::vector<int32_t>& idx, FlatBVH& out, int maxLeaf) : pb(pb), cen(cen), idx(idx), out(out), maxLeaf(maxLeaf) {}
 	int append(const FlatBVH& sub)                                 // returns the index the sub-tree's root gets
 	{
@@ -96,7 +97,7 @@ struct Builder
 		}
 		float leafCost = area(nb) * n;
 		int mid = -1;
-		if (bestAxis >= 0 && (n > maxLeaf || bestCost + area(nb) * 1.0f < leafCost))
+		if (bestAxis >= 0 && (n > maxLeaf || bestCost + area(nb) * travCost < leafCost))
 		{
 			float lo = cb.mn[bestAxis], hi = cb.mx[bestAxis]; float scale = NB / (hi - lo);
 			int a = bestAxis, bb = bestBin;
@@ -117,6 +118,7 @@ struct Builder
 		{
 			FlatBVH lo, ro;
 			Builder lb(pb, cen, idx, lo, maxLeaf), rb(pb, cen, idx, ro, maxLeaf);
+			lb.travCost = rb.travCost = travCost;
 			std::future<int> fl = std::async(std::launch::async, [&lb, start, mid, fork]() { return lb.build(start, mid, fork - 1); });
 			rb.build(mid, end, fork - 1);
 			fl.get();
@@ -144,6 +146,7 @@ void BuildBVH(const std::vector<FBounds3>& primBounds, FlatBVH& out, int maxLeaf
 	int fork = 4;                                                  // up to 16 concurrent subtree builds
 	if (const char* e = getenv("JETPBRT_BVH_THREADS")) { int v = atoi(e); fork = v <= 1 ? 0 : (v <= 2 ? 1 : (v <= 4 ? 2 : (v <= 8 ? 3 : 4))); }
 	Builder b(pb, cen, idx, out, maxLeaf);
+	if (const char* e = getenv("JETPBRT_SAH_TRAV_COST")) { const float v = (float)atof(e); if (v > 0.f && v <= 64.f) b.travCost = v; }
 	b.build(0, (int)pb.size(), fork);
 }
 

@@ -26,6 +26,9 @@ def main():
         kv = dict(x.split("=") for x in v.split()) if v.strip() else {}
         for k, val in kv.items():
             os.environ[k] = val
+        if any(k.startswith("JETPBRT_BVH_") or k.startswith("JETPBRT_SAH_") for k in kv):     # host tree parameters: build the scene again
+            hb = H.scenes.build_bunny(H.scenes.HostBackend("ab"), W, Hh) if name == "bunny" else H.SCENES[name](H.scenes.HostBackend("ab"), W, Hh)
+            sp = hb.flatten()
         try:
             ctx = jp.Context(0); ctx.upload(sp)
             p = jp.render_params(W, Hh, spp)
