@@ -124,7 +124,7 @@ def roofline_record(c, c1, value, spp_total, n, lanes, scene_key, prof):
             valu[k] = {"wave_insts_per_unit": pv["valu_insts_per_unit"], "achieved_Ginst_s": round(g, 1), "peak_Ginst_s": VALU_PEAK_GINST,
                        "frac": round(g / VALU_PEAK_GINST, 3), "lane_utilisation": pv.get("lane_utilisation"), "source": pv.get("valu_source")}
     if valu:
-        roof["valu"] = {"note": "wave64 VALU instructions issued per second vs 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles; kernels alone on the GPU (one stream lane)" if c1 is not None else "from the timed configuration", "kernels": valu}
+        roof["valu"] = {"note": "wave64 VALU instructions issued per second vs 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles; kernels alone on the GPU (one stream lane); under this load the shader clock sits at about 2.2 GHz (profiles/r02g_clocks_power.txt), so the peak is 8-9 % generous" if c1 is not None else "from the timed configuration", "kernels": valu}
     if c1 is not None:
         units1 = {"k_extend": B_PER_SEGMENT * c1.closest_rays, "k_shade": B_PER_SEGMENT * c1.closest_rays, "k_shadow": B_PER_SHADOW * c1.shadow_rays}
         dom1 = max(ms1, key=lambda k: ms1[k])
