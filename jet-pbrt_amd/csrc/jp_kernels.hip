@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, Rend
 					// FScene::Occluded scene.h:36-47: dir and distance recomputed from the sampled position
 					// (for an area light Normalize(target - position) is the very expression that produced ls.wi)
 					const V3 sdir = __float_as_int(lrad.w) == JP_LIGHT_AREA ? ls.wi : normalize(ls.pos - p);
-					const float dist = len(p - ls.pos);
+					const float dist = ls.dist >= 0.f ? ls.dist : len(p - ls.pos);
 					const V3 contrib = cmul(cmul(beta, f), ls.Li) * absdot(ls.wi, N) / ls.pdf;   // integrator.cc:369
 					if (k < rc.n_planes)
 					{

@@ -399,7 +399,7 @@ __device__ __forceinline__ void make_closure(MatPtr mats, int type, int mat, flo
 }
 
 // ---- lights ---------------------------------------------------------------------------------------------------------
-struct LightSample { V3 pos, wi; float pdf; V3 Li; };
+struct LightSample { V3 pos, wi; float pdf; V3 Li; float dist; };   // dist: |pos - p| where the sampler has it anyway (flat area lights), else < 0
 
 // FLight::Sample_Li for light `li` from surface point p with normal n (isect.normal, used by the sphere's
 // inside branch only).  light.h:199-216 (area), :265-291 (environment); shape sampling shape.h:124-145, 353-363,
@@ -407,7 +407,7 @@ struct LightSample { V3 pos, wi; float pdf; V3 Li; };
 template <typename PrimPtr, typename LightPtr>
 __device__ __forceinline__ LightSample sample_li(const SceneView& sc, PrimPtr prims, LightPtr lights, int li, V3 p, V3 n_isect, float ux, float uy)
 {
-	LightSample s; s.pos = mk(0, 0, 0); s.wi = mk(0, 0, 0); s.pdf = 0; s.Li = splat(0);
+	LightSample s; s.pos = mk(0, 0, 0); s.wi = mk(0, 0, 0); s.pdf = 0; s.Li = splat(0); s.dist = -1.f;
 	const float4 l0 = lights[2 * li], l1 = lights[2 * li + 1];
 	const V3 radiance = xyz(l0);
 	if (__float_as_int(l0.w) == JP_LIGHT_ENVIRONMENT)
@@ -464,7 +464,9 @@ __device__ __forceinline__ LightSample sample_li(const SceneView& sc, PrimPtr pr
 		if (dist2 == 0) pdf = 0;
 		else
 		{
-			wi = normalize(wi);
+			const float l = sqrtf(dist2);                         // Normalize(wi) = wi / sqrt(|wi|^2), with the length kept: FScene::Occluded's
+			wi = wi / l;                                          // |position - target| squares the negated differences -- the same bits
+			s.dist = l;
 			pdf *= dist2 / absdot(ln, -wi);
 			if (isinf(pdf)) pdf = 0;
 		}
