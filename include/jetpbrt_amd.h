@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define JP_ABI_VERSION 4
+#define JP_ABI_VERSION 5
 
 typedef enum JpStatus {
     JP_OK = 0,
@@ -134,6 +134,10 @@ typedef struct JpCounters {
     double   render_ms;          /* device time of the last jp_render*, HIP events on the context stream  */
     double   extend_ms, shade_ms, shadow_ms, other_ms;   /* per kernel class, when profiling is enabled   */
     uint64_t extend_launches, shade_launches, shadow_launches;
+    /* ABI 5: the fused schedule (k_path: ray generation and every bounce of a queue region in one launch, DESIGN.md "One schedule").
+     * When it runs, extend_ms / shade_ms / shadow_ms stay 0 and path_ms is the sum of the k_path launches. */
+    double   path_ms;
+    uint64_t path_launches;
 } JpCounters;
 
 /* what jp_upload_scene did with the hierarchy */
@@ -146,6 +150,9 @@ typedef struct JpBuildInfo {
                                     1 = glibc's FMA build, 2 = its build without contraction, 0 = none (own correctly
                                     rounded evaluation; films then differ from the host reference by rare path flips)  */
     int32_t lanes_last_render;   /* stream lanes the last jp_render* used (1-4; DESIGN.md "Stream lanes")                      */
+    /* ABI 5: the last jp_render* ran the fused schedule (1) or the per-bounce launches of rounds 1-2 (0: JETPBRT_FUSED=0, scenes
+     * whose tables do not fit LDS, the Whitted / debug integrators); region size and resident workgroups of that launch */
+    int32_t fused_last_render, fused_region, fused_workgroups;
 } JpBuildInfo;
 
 typedef struct JpContext JpContext;

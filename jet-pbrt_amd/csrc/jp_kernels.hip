@@ -19,7 +19,7 @@
 // Queues are SoA float4 arrays in HBM cut into one REGION per workgroup: block b reads region b of the input queue
 // and appends to region b of the output queues with a running offset, so compaction needs no global atomic and the
 // layout is deterministic.  Launches are asynchronous on one stream, no host round trip inside a batch.
-#include "jp_shading.h"
+#include "jp_common.h"
 #include "jp_xbsdf.h"
 
 #include <cstdio>
@@ -29,82 +29,6 @@
 #include <algorithm>
 #include <cmath>
 #include "jp_lbvh.h"
-
-using namespace jp;
-
-// ---------------------------------------------------------------------------------------------------------------------
-// device structures
-// ---------------------------------------------------------------------------------------------------------------------
-struct DevCounters
-{
-	unsigned int n_queue[2];                   // totals (host-side drain check for null-material scenes, statistics)
-	unsigned int n_shadow;
-	unsigned int pad;
-	unsigned long long closest, closest_hit, shadow, shadow_occ;
-};
-
-struct Queues
-{
-	float4 *ray_o[2], *ray_d[2], *beta[2];     // ping-pong ray queues: (o, slot) (d, flags) (beta, key)
-	float2 *hit;                               // (t, device prim index or -1) per queued ray
-	float4 *lacc;                              // per slot: radiance of the path so far
-	float4 *sh_o;                              // per shadow entry: (origin, slot | count << RenderConst::slot_bits)
-	float4 *sh_d, *sh_c;                       // plane k at [k * cap + q]: (dir, tmax), (contribution, visible flag)
-	unsigned int *blk_q[2], *blk_sh;           // per-block fill of the regions
-	unsigned int cap;                          // G * R entries per queue array
-	unsigned int R;                            // region capacity (multiple of JP_BLOCK); block b owns [b*R, (b+1)*R)
-};
-
-struct RenderConst
-{
-	int width, height, spp, max_depth;
-	unsigned int seed;
-	int band_rows, shard_index, shard_count;
-	int npix;            // pixels of this shard
-	int local_rows;
-	int s0, sbatch;      // first sample index and sample count of this batch
-	int n_planes;        // shadow ray planes (lights that can emit)
-	int tiled;           // pixel enumeration: 16 x 4 tiles (1) or row-major (0)
-	int slot_bits;       // a shadow entry's header word: slot in the low slot_bits bits, ray count above (27 + 5, or 24 + 8 for scenes with more than 31 emitting lights)
-	int sampler_debug;   // JP_SAMPLER_DEBUG: every draw is 0.5
-	int class_mask;      // material classes present in the scene (bit 0: none / null material, bit 1 + JP_MAT_*), k_shade<kSort>
-	int lane_index, lane_count, lane_rows;   // stream lanes: this launch owns the lane_rows-row groups g of the shard's rows with g % lane_count == lane_index
-};
-
-// one draw: the counter stream, or FDebugSampler's constant (sampler.h:109-127: GetFloat 0.5, GetFloat2 (0.5, 0.5), camera sample pixel + 0.5)
-__device__ __forceinline__ float rngf(const RenderConst& rc, uint32_t key, uint32_t dim) { return rc.sampler_debug ? 0.5f : jp_rng_float(key, dim); }
-
-#define FLAG_BOUNCE(f) ((f) & 0xff)
-#define FLAG_SPEC(f)   (((f) >> 8) & 1)
-#define FLAG_DIM(f)    (((unsigned)(f)) >> 16)
-#define MK_FLAGS(bounce, spec, dim) (((bounce) & 0xff) | ((spec) ? 0x100 : 0) | ((int)(dim) << 16))
-
-// pixel index of this shard -> film coordinates.  With rc.tiled (large scenes, image a whole number of 16 x 4 tiles) pixels
-// are enumerated tile by tile, so the 64 lanes of a wave start as a 16 x 4 patch of the image: camera rays and their first
-// shadow rays take nearly the same way through the scene (fewer divergent leaf visits, better cache reuse).
-__device__ __forceinline__ void pixel_of(const RenderConst& rc, int pix, int& x, int& y)
-{
-	int lx, r;
-	if (rc.tiled)
-	{
-		const int t = pix >> 6, i = pix & 63, tpr = rc.width >> 4;
-		const int ty = t / tpr, tx = t - ty * tpr;
-		lx = (tx << 4) + (i & 15); r = (ty << 2) + (i >> 4);
-	}
-	else { r = pix / rc.width; lx = pix - r * rc.width; }
-	x = lx;
-	if (rc.lane_count > 1) { const int m = r / rc.lane_rows; r = (rc.lane_index + m * rc.lane_count) * rc.lane_rows + (r - m * rc.lane_rows); }   // lane row -> shard row
-	const int j = r / rc.band_rows;
-	y = (rc.shard_index + j * rc.shard_count) * rc.band_rows + (r - j * rc.band_rows);
-}
-
-// wave-level take from an LDS counter: lane 0 adds the wave-uniform n, every lane gets the old value.  All 64 lanes must be active.
-__device__ __forceinline__ unsigned int wave_take(unsigned int* ctr, unsigned int n)
-{
-	unsigned int v = 0;
-	if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, n);
-	return (unsigned int)__builtin_amdgcn_readfirstlane((int)v);
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Wavefront-level sort: block-wide STABLE partition of a tile of kRPT x 256 queue entries by a small class key, with wave
@@ -200,7 +124,6 @@ __global__ void __launch_bounds__(JP_BLOCK) k_raygen(SceneView sc, Queues q, Ren
 // ---------------------------------------------------------------------------------------------------------------------
 // LDS layout of the traversal kernels: [stack: depth * 256 ints][nodes][prims]
 // ---------------------------------------------------------------------------------------------------------------------
-extern __shared__ float4 s_dyn[];      // 16-byte aligned base
 
 // kMode 0: BVH and primitives in global memory (L2 / Infinity Cache resident), one stack plane in LDS
 // kMode 1: BVH + primitives staged into LDS next to the stack
@@ -322,7 +245,6 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend(SceneView sc, Queues q, int
 #ifndef JP_SHADE_TILE
 #define JP_SHADE_TILE 8192
 #endif
-#define JP_SHADE_CLASSES 6
 template <bool kTab, bool kPrims, bool kStage, bool kSort>
 __global__ void __launch_bounds__(JP_BLOCK) k_shade(SceneView sc, Queues q, RenderConst rc, int cur, DevCounters* cnt)
 {
@@ -1276,6 +1198,8 @@ __global__ void __launch_bounds__(JP_BLOCK) k_resolve(Queues q, RenderConst rc, 
 	}
 }
 
+#include "jp_path.h"
+
 // ---------------------------------------------------------------------------------------------------------------------
 // k_tonemap8: gamma_encoding (film.h:24) of the resolved film on the device -> 3 bytes per pixel for the BMP / PPM writers of
 // FFilm::SaveAsImage (film.cc:45-145).  thr[k-1] is the smallest fp32 x in [0, 1] whose host-side gamma_encoding(x) is >= k
@@ -1369,7 +1293,7 @@ struct JpContext
 	bool tables_in_lds = false, stage_nee = false; size_t shade_lds_bytes = 0;
 	int class_mask = 0x3f; bool shade_sort = false;                                     // k_shade partitions its tiles by material class (scenes with more than one material kind)
 	// queues
-	Queues q; unsigned int cap = 0; int planes_alloc = 0; unsigned int blk_alloc = 0; int blocks_per_cu = 16;
+	Queues q = {}; unsigned int cap = 0; int planes_alloc = 0; unsigned int blk_alloc = 0; int blocks_per_cu = 16;
 	std::vector<void*> qbufs;
 	float4* d_pix_acc = nullptr; size_t pix_acc_n = 0;
 	// lane refill kernels: traversal-stack words per thread kept in LDS, the rest spills to global memory (WalkStack).  Measured on the
@@ -1393,6 +1317,10 @@ struct JpContext
 	// the scene tables (not owned) and writes its bands into its own film; the films are merged at the end.
 	std::vector<JpContext*> lanes; bool is_lane = false; unsigned long long own_samples = 0; bool bpc_from_env = false;
 	hipEvent_t ev_added = nullptr; bool added_valid = false; int last_lanes = 1;      // lanes used by the last render (1: this context alone)
+	// fused schedule (k_path, jp_path.h): region queues of the resident workgroups, the batch's radiance array, job counters
+	Queues fq = {}; std::vector<void*> fbufs; unsigned int fcap = 0; int fplanes = 0; size_t flacc_n = 0;
+	unsigned int* d_jobs = nullptr; size_t jobs_n = 0;
+	int last_fused = 0, last_region = 0, last_wgs = 0;
 };
 
 static void free_scene(JpContext* c)
@@ -1405,6 +1333,12 @@ static void free_queues(JpContext* c)
 {
 	for (void* p : c->qbufs) hipFree(p);
 	c->qbufs.clear(); c->cap = 0; c->planes_alloc = 0;
+}
+static void free_fused(JpContext* c)
+{
+	for (void* p : c->fbufs) hipFree(p);
+	c->fbufs.clear(); c->fcap = 0; c->fplanes = 0; c->flacc_n = 0;
+	if (c->d_jobs) hipFree(c->d_jobs); c->d_jobs = nullptr; c->jobs_n = 0;
 }
 
 // Which build of glibc's sinf / cosf / sincosf does this host run (jp_shading.h, sincosf_libm)?  The reference computes its
@@ -1505,6 +1439,7 @@ int jp_destroy_context(JpContext* c)
 	if (c->ev_added) hipEventDestroy(c->ev_added);
 	if (!c->is_lane) free_scene(c);
 	free_queues(c);
+	free_fused(c);
 	if (c->d_pix_acc) hipFree(c->d_pix_acc);
 	if (c->d_spill) hipFree(c->d_spill);
 	if (c->d_film) hipFree(c->d_film);
@@ -2050,7 +1985,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 // ---- render ---------------------------------------------------------------------------------------------------------------
 namespace
 {
-enum { CLS_EXTEND = 0, CLS_SHADE = 1, CLS_SHADOW = 2, CLS_OTHER = 3 };
+enum { CLS_EXTEND = 0, CLS_SHADE = 1, CLS_SHADOW = 2, CLS_OTHER = 3, CLS_PATH = 4 };
 
 int ensure_queues(JpContext* c, unsigned int cap, int planes, unsigned int nblocks)
 {
@@ -2287,10 +2222,166 @@ void sync_lane_scene(JpContext* c, JpContext* l)
 	l->profiling = c->profiling;
 }
 
+
+// ---- fused schedule: one k_path launch per batch (jp_path.h) --------------------------------------------------------------
+// OPT-IN (JETPBRT_FUSED=1; FScene / CLI: --fused).  Measured in round 3 (profiles/r03a_fused_ab.txt): films bit-identical to the
+// per-bounce launches, queue memory 1.2 GB instead of 13-40 GB -- and 20 % (Cornell) to 57 % (280k-triangle scene) SLOWER than three
+// stream lanes: k_path inherits k_shade's 168 registers, so the traversal phases run at 3 waves per SIMD instead of 8, and a region that
+// fits LDS-resident hit records and radiance (1024 paths) gives every phase of a late bounce less than one path per thread.
+// Which scenes: the path integrator on scenes whose tables fit LDS with <= 4 emitting lights (every scene of the reference),
+// traversal modes 2 (flat leaf list), 0 / 3 (binary + 8-wide trees, walkers) and 5 (reference semantics).  Mode 1 (a small tree
+// staged into LDS next to its stack) and larger tables keep the per-bounce launches.
+bool fused_eligible(const JpContext* c, const JpRenderParams* rp)
+{
+	const char* e = getenv("JETPBRT_FUSED");
+	if (!e || atoi(e) == 0) return false;
+	if (c->is_lane || !c->have_scene || rp->integrator != JP_INTEGRATOR_PATH) return false;
+	if (!c->tables_in_lds || !c->stage_nee) return false;
+	if (c->trav_mode == 2) return c->shade_prims_in_lds;
+	return c->trav_mode == 0 || c->trav_mode == 3 || c->trav_mode == 5;
+}
+
+typedef void (*PathKernel)(SceneView, Queues, RenderConst, PathConst, int*, DevCounters*);
+PathKernel path_kernel(const JpContext* c)
+{
+	const bool so = c->shade_sort;
+	switch (c->trav_mode)
+	{
+	case 2: return so ? k_path<2, 2, true, true, true> : k_path<2, 2, true, false, true>;
+	case 3: return so ? k_path<0, 3, false, true, true> : k_path<0, 3, false, false, true>;
+	case 5: return so ? k_path<5, 5, false, true, false> : k_path<5, 5, false, false, false>;
+	default: return so ? k_path<0, 0, false, true, true> : k_path<0, 0, false, false, true>;
+	}
+}
+
+int render_fused(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sync)
+{
+	if (rp->width <= 0 || rp->height <= 0 || rp->spp <= 0 || rp->max_depth < 0 || rp->max_depth > 200) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: bad width/height/spp/max_depth");
+	if (rp->sampler_mode != JP_SAMPLER_COUNTER && rp->sampler_mode != JP_SAMPLER_DEBUG) return fail(JP_ERR_UNSUPPORTED, "jp_render: the device path implements the counter sampler only (the sequential mt19937_64 stream is not reproducible in parallel)");
+	const int band = rp->band_rows > 0 ? rp->band_rows : 20;
+	const int scount = rp->shard_count > 1 ? rp->shard_count : 1;
+	const int sidx = scount > 1 ? rp->shard_index : 0;
+	if (sidx < 0 || sidx >= scount) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: shard_index out of range");
+	HIP_TRY(hipSetDevice(c->device));
+	const int nbands = (rp->height + band - 1) / band;
+	int local_rows = 0;
+	for (int b = sidx; b < nbands; b += scount) local_rows += std::min(band, rp->height - b * band);
+	const long long npix = (long long)local_rows * rp->width;
+
+	HIP_TRY(hipEventRecord(c->ev0, c->stream));
+	HIP_TRY(hipMemsetAsync(film_dev, 0, sizeof(float) * 3 * (size_t)rp->width * rp->height, c->stream));
+	HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(DevCounters), c->stream));
+	c->evused = 0; c->stamps.clear();
+	unsigned long long samples = 0;
+	c->last_fused = 1; c->last_lanes = 1;
+	if (npix > 0)
+	{
+		if (npix > (1 << 24)) return fail(JP_ERR_UNSUPPORTED, "jp_render: more than 2^24 pixels per shard");
+		const PathKernel kern = path_kernel(c);
+		const bool flat = c->trav_mode == 2;
+		const int modeE = flat ? 2 : (c->trav_mode == 5 ? 5 : 0);
+		// ---- batch: the radiance array holds one float4 per path of the batch (the only per-path array that outlives a job) ----
+		size_t freeB = 0, totalB = 0; hipMemGetInfo(&freeB, &totalB);
+		size_t budget = std::min<size_t>((size_t)4 << 30, (freeB + c->flacc_n * 16) / 4);
+		if (const char* e = getenv("JETPBRT_MAX_SLOTS")) { long long v = atoll(e); if (v > 0) budget = std::min<size_t>(budget, (size_t)v * 16); }
+		const size_t PMAX = (size_t)1 << 26;
+		const size_t pcap = std::min<size_t>(PMAX, std::max<size_t>((size_t)npix, budget / 16));
+		int sbatch = (int)std::max<long long>(1, std::min<long long>(rp->spp, (long long)(pcap / (size_t)npix)));
+		{ const int nb = (rp->spp + sbatch - 1) / sbatch; sbatch = (rp->spp + nb - 1) / nb; }       // equal batches
+		// ---- job shape: R paths = PG pixels x S samples.  A wave's 64 lanes are 64 neighbouring pixels of one sample. ----
+		unsigned int R = 1024;
+		if (const char* e = getenv("JETPBRT_REGION")) { int v = atoi(e); if (v >= JP_BLOCK && v <= 8192) R = (unsigned int)(v / JP_BLOCK) * JP_BLOCK; }
+		int S = 16;
+		if (const char* e = getenv("JETPBRT_JOB_SPP")) { int v = atoi(e); if (v >= 1 && v <= 128) S = v; }
+		const int n_tab = 2 * c->sv.n_lights + 4 * c->sv.n_mats + (c->sv.n_mats + 3) / 4, n_tab_all = n_tab + (flat ? 8 * c->sv.n_prims : 0);
+		const int deepE = c->stack_depth, deepS = c->trav_mode == 3 ? (int)(c->lds_bytes_shadow / (JP_BLOCK * sizeof(int))) : c->stack_depth;
+		const int ecap = flat ? 0 : std::min(deepE, c->stack_lds_words), scap = flat ? 0 : std::min(deepS, c->stack_lds_words);
+		PathLds L = path_lds_layout(modeE, n_tab_all, c->sv.n_prims, R, c->n_planes, ecap, scap, c->shade_sort);
+		while (L.total > 64 * 1024 && R > JP_BLOCK) { R -= JP_BLOCK; L = path_lds_layout(modeE, n_tab_all, c->sv.n_prims, R, c->n_planes, ecap, scap, c->shade_sort); }
+		if (L.total > 64 * 1024) return fail(JP_ERR_UNSUPPORTED, "jp_render: the fused schedule's LDS layout does not fit this scene (JETPBRT_FUSED=0 selects the per-bounce launches)");
+		S = std::max(1, std::min(S, std::min(sbatch, (int)(R / 64))));
+		int PG = (int)(R / (unsigned int)S); if (PG >= 64) PG &= ~63;
+		if ((long long)PG > npix) PG = (int)npix;
+		const int npg = (int)((npix + PG - 1) / PG), nsb = (sbatch + S - 1) / S;
+		const unsigned long long njobs = (unsigned long long)npg * nsb;
+		if (njobs >= (1ull << 32)) return fail(JP_ERR_UNSUPPORTED, "jp_render: too many jobs per batch");
+		// ---- resident workgroups: as many as the kernel's registers and LDS allow, persistent, taking jobs from a counter ----
+		HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
+		int per_cu = 0;
+		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, JP_BLOCK, L.total));
+		per_cu = std::max(1, per_cu);
+		if (const char* e = getenv("JETPBRT_FUSED_WGS")) { int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }
+		const unsigned int G = (unsigned int)std::min<unsigned long long>(njobs, (unsigned long long)c->n_cus * per_cu);
+		const unsigned int cap = G * R;
+		if (c->fcap < cap || c->fplanes < c->n_planes)
+		{
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			const unsigned int ncap = std::max(cap, c->fcap); const int npl = std::max(c->n_planes, c->fplanes);
+			const size_t keep_lacc = c->flacc_n; float4* keep = c->fq.lacc;
+			for (void* p : c->fbufs) if (p != (void*)keep) hipFree(p);
+			c->fbufs.clear(); if (keep) c->fbufs.push_back(keep);
+			c->fcap = 0; c->fplanes = 0;
+			Queues& q = c->fq; float4* lacc = keep; std::memset(&q, 0, sizeof(q)); q.lacc = lacc; c->flacc_n = keep_lacc;
+			auto alloc = [&](void** p, size_t bytes) -> bool { if (hipMalloc(p, bytes) != hipSuccess) return false; c->fbufs.push_back(*p); return true; };
+			bool ok = true;
+			for (int b = 0; b < 2 && ok; b++) ok = alloc((void**)&q.ray_o[b], (size_t)ncap * 16) && alloc((void**)&q.ray_d[b], (size_t)ncap * 16) && alloc((void**)&q.beta[b], (size_t)ncap * 16);
+			ok = ok && alloc((void**)&q.sh_o, (size_t)ncap * 16) && alloc((void**)&q.sh_d, (size_t)ncap * 16 * npl) && alloc((void**)&q.sh_c, (size_t)ncap * 16 * npl);
+			if (!ok) { free_fused(c); return fail(JP_ERR_DEVICE, "jp_render: out of device memory for the region queues"); }
+			c->fcap = ncap; c->fplanes = npl;
+		}
+		const size_t P = (size_t)sbatch * (size_t)npix;
+		if (c->flacc_n < P)
+		{
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			if (c->fq.lacc) { c->fbufs.erase(std::remove(c->fbufs.begin(), c->fbufs.end(), (void*)c->fq.lacc), c->fbufs.end()); hipFree(c->fq.lacc); c->fq.lacc = nullptr; c->flacc_n = 0; }
+			void* pl = nullptr; if (hipMalloc(&pl, P * 16) != hipSuccess) return fail(JP_ERR_DEVICE, "jp_render: out of device memory for the batch's radiance array");
+			c->fq.lacc = (float4*)pl; c->fbufs.push_back(pl); c->flacc_n = P;
+		}
+		c->fq.cap = c->fcap; c->fq.R = R;
+		const int nbatches = (rp->spp + sbatch - 1) / sbatch;
+		if (c->jobs_n < (size_t)nbatches) { HIP_TRY(hipStreamSynchronize(c->stream)); if (c->d_jobs) hipFree(c->d_jobs); c->d_jobs = nullptr; c->jobs_n = 0; HIP_TRY(hipMalloc((void**)&c->d_jobs, (size_t)nbatches * 4)); c->jobs_n = (size_t)nbatches; }
+		HIP_TRY(hipMemsetAsync(c->d_jobs, 0, (size_t)nbatches * 4, c->stream));
+		{   // spill area of the walkers' stacks beyond the words kept in LDS
+			const int deep = std::max(deepE, deepS);
+			const size_t need = !flat && deep > c->stack_lds_words ? (size_t)(deep - c->stack_lds_words) * G * JP_BLOCK : 1;
+			if (c->spill_words < need) { HIP_TRY(hipStreamSynchronize(c->stream)); if (c->d_spill) hipFree(c->d_spill); c->d_spill = nullptr; c->spill_words = 0; HIP_TRY(hipMalloc((void**)&c->d_spill, need * sizeof(int))); c->spill_words = need; }
+		}
+		if (c->pix_acc_n < (size_t)npix) { HIP_TRY(hipStreamSynchronize(c->stream)); if (c->d_pix_acc) hipFree(c->d_pix_acc); c->d_pix_acc = nullptr; HIP_TRY(hipMalloc((void**)&c->d_pix_acc, (size_t)npix * 16)); c->pix_acc_n = (size_t)npix; }
+
+		RenderConst rc; std::memset(&rc, 0, sizeof(rc));
+		rc.width = rp->width; rc.height = rp->height; rc.spp = rp->spp; rc.max_depth = rp->max_depth; rc.seed = rp->seed;
+		rc.band_rows = band; rc.shard_index = sidx; rc.shard_count = scount; rc.npix = (int)npix; rc.local_rows = local_rows; rc.n_planes = c->n_planes;
+		rc.lane_index = 0; rc.lane_count = 1; rc.lane_rows = 4; rc.class_mask = c->class_mask; rc.sampler_debug = rp->sampler_mode == JP_SAMPLER_DEBUG ? 1 : 0;
+		rc.slot_bits = JP_PATH_LI_BITS;
+		// 16 x 4 pixel tiles: a job's 64-pixel groups are patches of the image, so the lanes of a wave start as neighbours (camera
+		// rays and first shadow rays of large scenes share nodes).  JETPBRT_NO_TILES=1: row-major groups.
+		rc.tiled = (rp->width % 16 == 0 && local_rows % 4 == 0 && PG % 64 == 0 && !getenv("JETPBRT_NO_TILES") && (c->trav_mode != 2 || getenv("JETPBRT_TILES"))) ? 1 : 0;
+		PathConst pc; pc.R = R; pc.PG = PG; pc.S = S; pc.npg = npg; pc.nsb = nsb; pc.ecap = ecap; pc.scap = scap;
+		pc.max_iters = rp->max_depth + 1 + (c->has_null_material ? 64 : 0);
+		c->last_region = (int)R; c->last_wgs = (int)G;
+		for (int s0 = 0, bi = 0; s0 < rp->spp; s0 += sbatch, bi++)
+		{
+			rc.s0 = s0; rc.sbatch = std::min(sbatch, rp->spp - s0);
+			pc.nsb = (rc.sbatch + S - 1) / S; pc.job = c->d_jobs + bi;
+			const unsigned int g = (unsigned int)std::min<unsigned long long>((unsigned long long)npg * pc.nsb, (unsigned long long)G);
+			{ Stamper t(c, CLS_PATH); hipLaunchKernelGGL(kern, dim3(g), dim3(JP_BLOCK), L.total, c->stream, c->sv, c->fq, rc, pc, c->d_spill, c->d_cnt); }
+			HIP_TRY(hipGetLastError());
+			{ Stamper t(c, CLS_OTHER); hipLaunchKernelGGL(k_resolve, dim3((unsigned int)std::min<long long>(c->n_cus * 8, (npix + JP_BLOCK - 1) / JP_BLOCK)), dim3(JP_BLOCK), 0, c->stream, c->fq, rc, c->d_pix_acc, film_dev, s0 == 0 ? 1 : 0, s0 + rc.sbatch >= rp->spp ? 1 : 0); }
+			HIP_TRY(hipGetLastError());
+			samples += (unsigned long long)rc.sbatch * (unsigned long long)npix;
+		}
+	}
+	HIP_TRY(hipEventRecord(c->ev1, c->stream));
+	c->own_samples = samples;
+	if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+	return JP_OK;
+}
+
 int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sync)
 {
 	if (!c || !rp || !film_dev) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: null argument");
-	c->last_lanes = 1;
+	c->last_lanes = 1; c->last_fused = 0;
+	if (fused_eligible(c, rp)) return render_fused(c, rp, film_dev, sync);
 	// lanes: the shard's rows in groups of 4 dealt round-robin to L contexts.  Default: 3 lanes when each gets >= 16 groups and
 	// full-size batches, else 2, else 1 (measured on the benchmark frame: 1 lane 2.19, 2 lanes 2.70, 3 lanes 2.82, 4 lanes 2.38
 	// Gsamples/s).  JETPBRT_LANES = 1 .. 4 forces a count, JETPBRT_LANE_ROWS the group height.
@@ -2363,6 +2454,7 @@ int finish_one(JpContext* c, JpCounters& o)
 		if (s.cls == CLS_EXTEND) { o.extend_ms += t; o.extend_launches++; }
 		else if (s.cls == CLS_SHADE) { o.shade_ms += t; o.shade_launches++; }
 		else if (s.cls == CLS_SHADOW) { o.shadow_ms += t; o.shadow_launches++; }
+		else if (s.cls == CLS_PATH) { o.path_ms += t; o.path_launches++; }
 		else o.other_ms += t;
 	}
 	return JP_OK;
@@ -2437,6 +2529,7 @@ int jp_get_build_info(JpContext* c, JpBuildInfo* out)
 	if (!c->have_scene) return fail(JP_ERR_NO_SCENE, "jp_get_build_info: no scene uploaded");
 	out->built_on_device = c->build_on_device ? 1 : 0; out->traversal_mode = c->trav_mode; out->bvh_nodes = c->bvh_nodes; out->bvh_height = c->bvh_height;
 	out->device_build_ms = c->build_ms; out->libm_sincosf = c->sincosf_mode; out->lanes_last_render = c->last_lanes;
+	out->fused_last_render = c->last_fused; out->fused_region = c->last_region; out->fused_workgroups = c->last_wgs;
 	return JP_OK;
 }
 
@@ -2511,6 +2604,16 @@ extern "C" int jp_dbg_shade_timing(unsigned long long* out16)
 	unsigned long long z[16] = { 0 };
 	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_shade_t), sizeof(z)) != hipSuccess) return -1;
 	if (hipMemcpyToSymbol(HIP_SYMBOL(g_shade_t), z, sizeof(z)) != hipSuccess) return -1;
+	return 0;
+}
+#endif
+
+#ifdef JP_PATH_TIMING
+extern "C" int jp_dbg_path_timing(unsigned long long* out16)
+{
+	unsigned long long z[16] = { 0 };
+	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_path_t), sizeof(z)) != hipSuccess) return -1;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(g_path_t), z, sizeof(z)) != hipSuccess) return -1;
 	return 0;
 }
 #endif

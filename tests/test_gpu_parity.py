@@ -1027,3 +1027,49 @@ def test_wavefront_sorts_and_lane_refill_do_not_change_the_film(H, gpu_ctx, monk
         assert rm == 5 and np.array_equal(r0.view(np.uint32), r1.view(np.uint32)) and rc0 == rc1, (r, v)
     r2, rc2, _ = render({"JETPBRT_PERSIST": "16", "JETPBRT_STACK_LDS": "2"}, rsp)          # the reference tree's walker on a spilling stack
     assert np.array_equal(r0.view(np.uint32), r2.view(np.uint32)) and rc0 == rc2
+
+
+# ---- round 3: the fused schedule (k_path, csrc/jp_path.h; opt-in with JETPBRT_FUSED=1) -----------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "cornell_lambert", "bunny_small", "disks", "lights"])
+def test_fused_schedule_renders_the_same_film(H, gpu_ctx, monkeypatch, name):
+    """k_path runs ray generation and every bounce of a queue region in ONE launch (hit records and the paths' radiance in LDS,
+    persistent workgroups taking (pixel group, sample block) jobs from a counter).  Every path computes what it computes in the
+    per-bounce launches: film and ray statistics bit-identical, for every region size / job shape / workgroup count, for band
+    shards, for traversal through the flat leaf list (Cornell), the binary + 8-wide trees (forced on the small mesh), the
+    reference tree, a scene with a null-material primitive (extra iterations inside the launch) and point / direction lights"""
+    W, Hh, spp = 96, 72, 10
+    hb, sp = _scene(H, name, W, Hh)
+
+    def render(env, scene_ptr=sp, params=None):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = H.jp.Context(0)
+        try:
+            ctx.upload(scene_ptr)
+            film = ctx.render(params or H.jp.render_params(W, Hh, spp, 5, 31)); c = ctx.counters(); bi = ctx.build_info()
+        finally:
+            ctx.close()
+            for k in env:
+                monkeypatch.delenv(k)
+        return film, (c.samples, c.closest_rays, c.closest_hits, c.shadow_rays, c.shadow_occluded), bi
+
+    for trav in ({}, {"JETPBRT_TRAVERSAL": "0"}, {"JETPBRT_TRAVERSAL": "3"}):
+        base, cnt, bi0 = render(dict(trav))
+        if bi0.traversal_mode == 1:
+            continue                                               # a tree staged into LDS next to its stack keeps the per-bounce launches
+        assert bi0.fused_last_render == 0
+        for env in ({}, {"JETPBRT_REGION": "256"}, {"JETPBRT_REGION": "2048", "JETPBRT_JOB_SPP": "3"}, {"JETPBRT_JOB_SPP": "1"},
+                    {"JETPBRT_FUSED_WGS": "1"}, {"JETPBRT_MAX_SLOTS": str(3 * W * Hh)}, {"JETPBRT_STACK_LDS": "2"}, {"JETPBRT_SHADE_SORT": "0"}):
+            film, c2, bi = render(dict(trav, JETPBRT_FUSED="1", **env))
+            assert bi.fused_last_render == 1 and bi.traversal_mode == bi0.traversal_mode, (trav, env)
+            assert np.array_equal(film.view(np.uint32), base.view(np.uint32)) and c2 == cnt, (trav, env)
+    # band shards (multi-GPU split) and the reference tree
+    ps = H.jp.render_params(W, Hh, spp, 5, 31, band_rows=7, shard_index=1, shard_count=3)
+    a, ca, _ = render({}, params=ps); b, cb, bi = render({"JETPBRT_FUSED": "1"}, params=ps)
+    if bi.fused_last_render:
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ca == cb
+    rb, rsp = _reference_tree_scene(H, name, W, Hh)
+    r0, rc0, _ = render({}, rsp); r1, rc1, bi = render({"JETPBRT_FUSED": "1"}, rsp)
+    assert bi.fused_last_render == 1 and bi.traversal_mode == 5
+    assert np.array_equal(r0.view(np.uint32), r1.view(np.uint32)) and rc0 == rc1

@@ -21,7 +21,7 @@ def test_abi_exports_every_declared_symbol(H):
     lib = C.CDLL(H.jp.HIP_LIB_PATH)
     for n in names:
         assert hasattr(lib, n), "libjetpbrt_amd.so does not export %s" % n
-    assert lib.jp_abi_version() == 4
+    assert lib.jp_abi_version() == 5
 
 
 def test_abi_struct_layout_matches_header(H):
