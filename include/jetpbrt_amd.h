@@ -153,6 +153,8 @@ typedef struct JpBuildInfo {
     /* ABI 5: the last jp_render* ran the fused schedule (1) or the per-bounce launches of rounds 1-2 (0: JETPBRT_FUSED=0, scenes
      * whose tables do not fit LDS, the Whitted / debug integrators); region size and resident workgroups of that launch */
     int32_t fused_last_render, fused_region, fused_workgroups;
+    int32_t q4_nodes;            /* ABI 5: nodes of the 4-wide quantised tree the closest-hit rays walk (0: none; scenes of <= 1024 primitives, device-built
+                                    and reference-semantics trees, JETPBRT_Q4=0) */
 } JpBuildInfo;
 
 typedef struct JpContext JpContext;

@@ -69,6 +69,7 @@ struct SceneView
 	const float4* flat; int n_flat;        // tiny scenes: <= 32 leaf boxes with the bit set of their primitives (<= 64), flat_boxes
 	const uint4* wide; int n_wide;          // large scenes: 8-wide quantised nodes, 5 x 16 bytes each (traverse_wide)
 	const float4* cut; int n_cut;           // other than tiny scenes: boxes of the <= 16 largest subtrees below the root in the flat_boxes layout (one bit each): the sort key of k_extend_sort / k_shadow_sort
+	const uint4* q4; int n_q4;              // large scenes: 4-wide tree with quantised child boxes, 4 x 16 bytes per node (Walker<4>)
 };
 
 // ---- shape intersection: exact restatements ---------------------------------------------------------------------
@@ -571,5 +572,100 @@ template <> struct Walker<3>
 		else done = true;
 	}
 };
+
+// ---- round 3: 4-wide tree with quantised child boxes for the CLOSEST-HIT rays of large scenes ------------------------------------
+// The lane-refill kernels on the 280k-triangle scene are bound by the vector-memory path: every lane fetches its own 64-byte node per
+// step, ~19 cycles per 1-KiB wave load instruction with 32 waves per CU (profiles/r02g_c3_pmc_sq.txt: 562 node / leaf steps of ~2,400
+// cycles per wave), and a binary node spends those 64 bytes on TWO child boxes.  Here a 64-byte node holds FOUR children:
+//   q0 = (p.x, p.y, p.z, e.x | e.y << 8 | e.z << 16 | valid << 24)     node origin, per-axis scale exponents, valid-child mask
+//   q1 = (ref0, ref1, ref2, ref3)        child references in the binary tree's encoding: >= 0 node index, < 0 leaf (first << 4 | count - 1)
+//   q2 = (lo.x[0..3], lo.y[0..3], lo.z[0..3], hi.x[0..3])   q3 = (hi.y[0..3], hi.z[0..3], -, -)      one byte per child and plane
+// child plane = p + q * 2^e, rounded outward by the host until the fp32 value the device computes is conservative (as for the 8-wide
+// tree).  Unlike the 8-wide walk (octant order) the hit children are visited in EXACT near-to-far order of their dequantised entry
+// distances: each hit child's rank among the hits (six comparisons) says where it goes -- rank 0 is walked next, the others onto the
+// stack, farthest first.  Half the node steps per ray of the binary walk for the same bytes per step.  The quantised boxes contain
+// the binary tree's boxes, so every hit the binary walk finds is found (never a dropped hit; fringe hits as DESIGN.md "Numerics").
+template <> struct Walker<4>
+{
+	V3 o, d; float ix, iy, iz, tmin, tmax; int cur, sp, hit; bool done;
+	__device__ __forceinline__ void start(V3 o_, V3 d_, float tmin_, float tmax_)
+	{ o = o_; d = d_; ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z; tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; done = false; }
+	__device__ __forceinline__ bool heavy() const { return cur < 0; }                 // next step is a leaf (primitive tests), not a node
+	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, const WalkStack& stack)
+	{
+		if (cur >= 0)
+		{
+			const uint4* __restrict__ nd = sc.q4 + 4 * (size_t)cur;
+			const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2]; const uint2 q3 = *(const uint2*)(nd + 3);
+			// slab distance of plane byte q on axis x: ((p.x + q * 2^e.x) - o.x) / d.x = q * A.x + B.x with A = 2^e / d, B = (p - o) / d: one
+			// conversion and one fma per plane.  Rounding: |error| <~ 3e-7 * (node extent) / |d| -- covered by the host's padding of every child
+			// box by 1e-6 of the node's extent before it is quantised outward (jp_upload_scene), on top of the 2e-6 relative slack below.
+			const float ax = __uint_as_float((q0.w & 0xffu) << 23) * ix, ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * iy, az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * iz;
+			const float bx = (__uint_as_float(q0.x) - o.x) * ix, by = (__uint_as_float(q0.y) - o.y) * iy, bz = (__uint_as_float(q0.z) - o.z) * iz;
+			// near / far plane of each axis by the sign of the direction: min / max of the two slab distances without computing both orders
+			// (a NaN -- 0 * inf on an axis the ray is parallel to -- is dropped by fmaxf / fminf: that axis then does not constrain, conservative)
+			const bool nx = ix >= 0.f, ny = iy >= 0.f, nz = iz >= 0.f;
+			const unsigned int axn = nx ? q2.x : q2.w, axf = nx ? q2.w : q2.x;
+			const unsigned int ayn = ny ? q2.y : q3.x, ayf = ny ? q3.x : q2.y;
+			const unsigned int azn = nz ? q2.z : q3.y, azf = nz ? q3.y : q2.z;
+			float tn[4]; bool hc[4]; int nh = 0;
+			#pragma unroll
+			for (int i = 0; i < 4; i++)
+			{
+				const int sh = 8 * i;
+				const float x0 = fmaf((float)((axn >> sh) & 0xffu), ax, bx), x1 = fmaf((float)((axf >> sh) & 0xffu), ax, bx);
+				const float y0 = fmaf((float)((ayn >> sh) & 0xffu), ay, by), y1 = fmaf((float)((ayf >> sh) & 0xffu), ay, by);
+				const float z0 = fmaf((float)((azn >> sh) & 0xffu), az, bz), z1 = fmaf((float)((azf >> sh) & 0xffu), az, bz);
+				const float t0 = fmaxf(fmaxf(x0, y0), fmaxf(z0, tmin));
+				const float tf = fminf(fminf(x1, y1), fminf(z1, tmax));
+				hc[i] = ((q0.w >> (24 + i)) & 1u) && t0 <= tf * 1.000002f;
+				tn[i] = hc[i] ? fminf(t0, 3.0e38f) : JP_INF;             // a missed child ranks behind every hit one
+				nh += hc[i] ? 1 : 0;
+			}
+			if (nh == 0)
+			{
+				if (sp > 0) { sp--; cur = stack.get(sp); } else done = true;
+				return;
+			}
+			const int ref[4] = { (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w };
+			if (kAnyHit)
+			{   // order irrelevant: the first hit child is walked next, the others go on the stack
+				int k = 0;
+				#pragma unroll
+				for (int i = 0; i < 4; i++) if (hc[i]) { if (k == 0) cur = ref[i]; else stack.put(sp + k - 1, ref[i]); k++; }
+			}
+			else
+			{   // rank of a child = number of children entered before it (ties by child number: a total order; six comparisons); the hit
+				// children have the ranks 0 .. nh-1
+				int r[4] = { 0, 0, 0, 0 };
+				#pragma unroll
+				for (int i = 0; i < 4; i++)
+					#pragma unroll
+					for (int j = i + 1; j < 4; j++) { const bool first = tn[i] <= tn[j]; r[j] += first ? 1 : 0; r[i] += first ? 0 : 1; }
+				#pragma unroll
+				for (int i = 0; i < 4; i++)
+					if (hc[i]) { if (r[i] == 0) cur = ref[i]; else stack.put(sp + nh - 1 - r[i], ref[i]); }
+			}
+			sp += nh - 1;
+		}
+		else
+		{   // one leaf per step (Walker<0>)
+			const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
+			for (int k = 0; k < count; k++)
+				if (prim_hit<4>(sc.prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) { done = true; return; } }
+			if (sp > 0) { sp--; cur = stack.get(sp); } else done = true;
+		}
+	}
+};
+
+// a walker driven to the end by one lane (k_trace, k_other): the same steps as under lane refill
+template <int kMode, bool kAnyHit>
+__device__ __forceinline__ int walk_ray(const SceneView& sc, V3 o, V3 d, float tmin, float& tmax, const WalkStack& stack)
+{
+	Walker<kMode> w; w.start(o, d, tmin, tmax);
+	while (!w.done) w.template step<kAnyHit>(sc, stack);
+	tmax = w.tmax;
+	return w.hit;
+}
 
 } // namespace jp

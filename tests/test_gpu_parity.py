@@ -1059,6 +1059,10 @@ def test_fused_schedule_renders_the_same_film(H, gpu_ctx, monkeypatch, name):
         if bi0.traversal_mode == 1:
             continue                                               # a tree staged into LDS next to its stack keeps the per-bounce launches
         assert bi0.fused_last_render == 0
+        probe, cp, bip = render(dict(trav, JETPBRT_FUSED="1"))
+        if not bip.fused_last_render:                              # five emitting lights (k_path stages <= 4 shadow rays per path): the per-bounce launches serve
+            assert name == "lights" and np.array_equal(probe.view(np.uint32), base.view(np.uint32)) and cp == cnt
+            continue
         for env in ({}, {"JETPBRT_REGION": "256"}, {"JETPBRT_REGION": "2048", "JETPBRT_JOB_SPP": "3"}, {"JETPBRT_JOB_SPP": "1"},
                     {"JETPBRT_FUSED_WGS": "1"}, {"JETPBRT_MAX_SLOTS": str(3 * W * Hh)}, {"JETPBRT_STACK_LDS": "2"}, {"JETPBRT_SHADE_SORT": "0"}):
             film, c2, bi = render(dict(trav, JETPBRT_FUSED="1", **env))
@@ -1071,5 +1075,62 @@ def test_fused_schedule_renders_the_same_film(H, gpu_ctx, monkeypatch, name):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ca == cb
     rb, rsp = _reference_tree_scene(H, name, W, Hh)
     r0, rc0, _ = render({}, rsp); r1, rc1, bi = render({"JETPBRT_FUSED": "1"}, rsp)
-    assert bi.fused_last_render == 1 and bi.traversal_mode == 5
+    assert bi.traversal_mode == 5 and (bi.fused_last_render == 1 or name == "lights")
     assert np.array_equal(r0.view(np.uint32), r1.view(np.uint32)) and rc0 == rc1
+
+
+# ---- round 3: the 4-wide quantised tree (Walker<4>, csrc/jp_device.h) -----------------------------------------------------------
+def test_four_wide_quantised_tree_hit_records_and_film(H, monkeypatch):
+    """closest-hit (and shadow) rays of scenes with more than 1024 primitives walk a 4-wide tree with 8-bit child boxes in exact
+    near-to-far order.  On a 12k-triangle version of the mesh scene: hit records of 200k random rays (axis-parallel ones included)
+    bit-exact against the oracle (another topology), identical to the binary walk's; films with the tree on / off and with the shadow
+    rays on the 8-wide tree instead are bit-identical; a stack that spills to global memory after 2 words changes nothing"""
+    W, Hh, spp = 160, 120, 8
+    hb = H.scenes.build_bunny(H.scenes.HostBackend("q4"), W, Hh, n_lon=40, n_lat=38)
+    sp = hb.flatten()
+    assert sp.contents.n_primitives > 1024
+
+    def ctx_with(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = H.jp.Context(0); c.upload(sp)
+        for k in env:
+            monkeypatch.delenv(k)
+        return c
+
+    rng = np.random.default_rng(11)
+    m = 200000
+    o = (rng.random((m, 3)) * [500, 300, 500] - [250, -10, 250]).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[: m // 50, 0] = 0.0; d[m // 50: m // 25, 1] = 0.0; d[m // 25: m // 20, 2] = 0.0
+    tmin = np.full(m, 0.001, np.float32); tmax = np.where(rng.random(m) < 0.5, np.inf, rng.random(m) * 400).astype(np.float32)
+    c4 = ctx_with({})
+    try:
+        assert c4.build_info().traversal_mode == 3 and c4.build_info().q4_nodes > 1000
+        hit, t, prim, nrm = c4.trace(o, d, tmin, tmax)
+        monkeypatch.setenv("JETPBRT_TRACE_BINARY", "1")
+        hit2, t2, prim2, nrm2 = c4.trace(o, d, tmin, tmax)
+        monkeypatch.delenv("JETPBRT_TRACE_BINARY")
+        film4 = c4.render(H.jp.render_params(W, Hh, spp, 5, 9)); cnt4 = c4.counters()
+    finally:
+        c4.close()
+    L = H.oracle_lib(); oh = L.jp_oracle_scene_new(sp)
+    ohit = np.zeros(m, np.int32); ot = np.zeros(m, np.float32); oprim = np.zeros(m, np.int32); onrm = np.zeros((m, 3), np.float32); opos = np.zeros((m, 3), np.float32)
+    L.jp_oracle_trace(oh, m, H.ptr(o), H.ptr(d), H.ptr(tmin), H.ptr(tmax), H.ptr(ohit), H.ptr(ot), H.ptr(oprim), H.ptr(onrm), H.ptr(opos))
+    L.jp_oracle_scene_free(oh)
+    assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    assert (prim == oprim).mean() > 0.9999
+    assert np.array_equal(hit, hit2) and np.array_equal(t.view(np.uint32), t2.view(np.uint32)) and (prim == prim2).mean() > 0.9999
+    for env in ({"JETPBRT_Q4": "0"}, {"JETPBRT_Q4_SHADOW": "0"}, {"JETPBRT_STACK_LDS": "2"}, {"JETPBRT_PERSIST": "8", "JETPBRT_VOTE": "0"}):
+        c = ctx_with(env)
+        try:
+            assert (c.build_info().q4_nodes == 0) == (env.get("JETPBRT_Q4") == "0")
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            film = c.render(H.jp.render_params(W, Hh, spp, 5, 9)); cnt = c.counters()
+            for k in env:
+                monkeypatch.delenv(k)
+        finally:
+            c.close()
+        assert np.array_equal(film.view(np.uint32), film4.view(np.uint32)), env
+        assert (cnt.closest_rays, cnt.closest_hits, cnt.shadow_rays, cnt.shadow_occluded) == (cnt4.closest_rays, cnt4.closest_hits, cnt4.shadow_rays, cnt4.shadow_occluded), env
