@@ -155,6 +155,8 @@ typedef struct JpBuildInfo {
     int32_t fused_last_render, fused_region, fused_workgroups;
     int32_t q4_nodes;            /* ABI 5: nodes of the 4-wide quantised tree the closest-hit rays walk (0: none; scenes of <= 1024 primitives, device-built
                                     and reference-semantics trees, JETPBRT_Q4=0) */
+    int32_t libm_xbsdf;          /* ABI 5: bit 0: the device reproduces the host libm's logf / expf / powf / acosf / atanf / tanf bit for bit (the BSDF
+                                    classes behind jp_bsdf that call them are then bit-exact against the reference); bit 1: with libm's FMA build */
 } JpBuildInfo;
 
 typedef struct JpContext JpContext;
@@ -164,6 +166,8 @@ int  jp_abi_version(void);
 /* which build of the host libm's sinf / cosf / sincosf the device will reproduce (JpBuildInfo.libm_sincosf): probes the
  * host's libm against the library's transcription of glibc's algorithm on 200,000 arguments.  Pure host code, no GPU needed. */
 int  jp_probe_libm_sincosf(void);
+/* the same for logf / expf / powf / acosf / atanf / tanf (JpBuildInfo.libm_xbsdf) */
+int  jp_probe_libm_xbsdf(void);
 
 /* one context per process per GPU (device_id = LOCAL_RANK) */
 int  jp_create_context(int device_id, JpContext** out);

@@ -593,6 +593,7 @@ template <> struct Walker<4>
 	__device__ __forceinline__ bool heavy() const { return cur < 0; }                 // next step is a leaf (primitive tests), not a node
 	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, const WalkStack& stack)
 	{
+		bool pop = true;
 		if (cur >= 0)
 		{
 			const uint4* __restrict__ nd = sc.q4 + 4 * (size_t)cur;
@@ -622,39 +623,47 @@ template <> struct Walker<4>
 				tn[i] = hc[i] ? fminf(t0, 3.0e38f) : JP_INF;             // a missed child ranks behind every hit one
 				nh += hc[i] ? 1 : 0;
 			}
-			if (nh == 0)
-			{
-				if (sp > 0) { sp--; cur = stack.get(sp); } else done = true;
-				return;
-			}
 			const int ref[4] = { (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w };
-			if (kAnyHit)
-			{   // order irrelevant: the first hit child is walked next, the others go on the stack
-				int k = 0;
-				#pragma unroll
-				for (int i = 0; i < 4; i++) if (hc[i]) { if (k == 0) cur = ref[i]; else stack.put(sp + k - 1, ref[i]); k++; }
-			}
+			// rank of a child = number of children entered before it (ties by child number: a total order; six comparisons); the hit
+			// children have the ranks 0 .. nh-1.  Any-hit rays: the children's own order (rank among the hit ones).
+			int r[4] = { 0, 0, 0, 0 };
+			if (kAnyHit) { r[1] = hc[0] ? 1 : 0; r[2] = r[1] + (hc[1] ? 1 : 0); r[3] = r[2] + (hc[2] ? 1 : 0); }
 			else
-			{   // rank of a child = number of children entered before it (ties by child number: a total order; six comparisons); the hit
-				// children have the ranks 0 .. nh-1
-				int r[4] = { 0, 0, 0, 0 };
+			{
 				#pragma unroll
 				for (int i = 0; i < 4; i++)
 					#pragma unroll
 					for (int j = i + 1; j < 4; j++) { const bool first = tn[i] <= tn[j]; r[j] += first ? 1 : 0; r[i] += first ? 0 : 1; }
+			}
+			// rank 0 is walked next, the others go on the stack, farthest first.  No branch per child: while the three possible entries
+			// fit the LDS part of the stack, every child stores -- the ones with nothing to push into the word behind the stack's LDS part
+			// (the kernels allocate cap + 1 words per thread)
+			if (sp + 3 <= stack.cap)
+			{
+				#pragma unroll
+				for (int i = 0; i < 4; i++)
+				{
+					const bool push = hc[i] && r[i] != 0;
+					stack.lds[(push ? sp + nh - 1 - r[i] : stack.cap) * JP_BLOCK] = ref[i];
+					cur = (hc[i] && r[i] == 0) ? ref[i] : cur;
+				}
+			}
+			else
+			{
 				#pragma unroll
 				for (int i = 0; i < 4; i++)
 					if (hc[i]) { if (r[i] == 0) cur = ref[i]; else stack.put(sp + nh - 1 - r[i], ref[i]); }
 			}
-			sp += nh - 1;
+			sp += nh > 0 ? nh - 1 : 0;
+			pop = nh == 0;
 		}
 		else
 		{   // one leaf per step (Walker<0>)
 			const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
 			for (int k = 0; k < count; k++)
 				if (prim_hit<4>(sc.prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) { done = true; return; } }
-			if (sp > 0) { sp--; cur = stack.get(sp); } else done = true;
 		}
+		if (pop) { if (sp > 0) { sp--; cur = stack.get(sp); } else done = true; }
 	}
 };
 

@@ -195,7 +195,7 @@ template <> struct SceneAccess<3>
 template <> struct SceneAccess<4>
 {   // the 4-wide quantised tree, one ray per lane to the end (k_trace); the whole stack in LDS
 	WalkStack stack;
-	__device__ __forceinline__ SceneAccess(const SceneView&, int depth) { stack.lds = (int*)s_dyn + threadIdx.x; stack.spill = nullptr; stack.cap = depth; stack.stride = 0; }
+	__device__ __forceinline__ SceneAccess(const SceneView&, int depth) { stack.lds = (int*)s_dyn + threadIdx.x; stack.spill = nullptr; stack.cap = depth - 1; stack.stride = 0; }   // (the last word: Walker<4>'s dump slot)
 	template <bool kAnyHit> __device__ __forceinline__ int trace(const SceneView& sc, V3 o, V3 d, float tmin, float& tmax) const
 	{ return walk_ray<4, kAnyHit>(sc, o, d, tmin, tmax, stack); }
 };
@@ -806,7 +806,7 @@ template <int kMode, int kRefill, bool kVote>
 __global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queues q, int cur_q, int stack_cap, int* spill, DevCounters* cnt)
 {
 	__shared__ unsigned int s_next;
-	const WalkStack stack = { (int*)s_dyn + threadIdx.x, spill + blockIdx.x * JP_BLOCK + threadIdx.x, stack_cap, gridDim.x * JP_BLOCK };
+	const WalkStack stack = { (int*)s_dyn + threadIdx.x, spill + blockIdx.x * JP_BLOCK + threadIdx.x, kMode == 4 ? stack_cap - 1 : stack_cap, gridDim.x * JP_BLOCK };   // Walker<4>: the last LDS word is its dump slot
 	const unsigned int b = blockIdx.x, n = q.blk_q[cur_q][b], rbase = b * q.R;
 	if (b == 0 && threadIdx.x == 0) { cnt->closest += cnt->n_queue[cur_q]; cnt->n_queue[cur_q ^ 1] = 0; cnt->n_shadow = 0; }
 	if (threadIdx.x == 0) s_next = 0;
@@ -856,7 +856,7 @@ template <int kMode, int kRefill, bool kVote>
 __global__ void __launch_bounds__(JP_BLOCK) k_shadow_persist(SceneView sc, Queues q, RenderConst rc, int stack_cap, int* spill, DevCounters* cnt)
 {
 	__shared__ unsigned int s_next;
-	const WalkStack stack = { (int*)s_dyn + threadIdx.x, spill + blockIdx.x * JP_BLOCK + threadIdx.x, stack_cap, gridDim.x * JP_BLOCK };
+	const WalkStack stack = { (int*)s_dyn + threadIdx.x, spill + blockIdx.x * JP_BLOCK + threadIdx.x, kMode == 4 ? stack_cap - 1 : stack_cap, gridDim.x * JP_BLOCK };   // Walker<4>: the last LDS word is its dump slot
 	unsigned int* s_occ = (unsigned int*)s_dyn + stack_cap * JP_BLOCK;   // bit r set: ray r is occluded
 	const unsigned int b = blockIdx.x, E = q.blk_sh[b], rbase = b * q.R;
 	const unsigned int NP = (unsigned int)rc.n_planes, total = E * NP;
@@ -1297,7 +1297,7 @@ struct JpContext
 	bool use_q4 = false, q4_shadow = false;                                            // closest-hit (and, as an experiment, shadow) rays walk the 4-wide quantised tree (Walker<4>)
 	bool vote = false; int persist = 0;                                             // lane refill in the closest-hit traversal of large scenes (k_extend_persist): refill threshold, 0 = off
 	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr, *d_shade_tab = nullptr;
-	int n_planes = 1; bool has_null_material = false; int sincosf_mode = 0;
+	int n_planes = 1; bool has_null_material = false; int sincosf_mode = 0, libm_mode = 0;
 	bool build_on_device = false; float build_ms = 0.f; int bvh_height = 0, bvh_nodes = 0;
 	bool tables_in_lds = false, stage_nee = false; size_t shade_lds_bytes = 0;
 	int class_mask = 0x3f; bool shade_sort = false;                                     // k_shade partitions its tiles by material class (scenes with more than one material kind)
@@ -1383,6 +1383,51 @@ static int probe_host_sincosf()
 	return cached;
 }
 
+// Do jp_libm.h's logf / expf / powf / acosf / atanf / tanf reproduce the host's libm (jp_xbsdf.h: g_libm_mode)?  Bit 0: all six do on
+// every probe argument; bit 1: with the FMA build of the first three (glibc's IFUNC picks it on CPUs with FMA + AVX2; the two builds
+// differ on about one argument in 10^8, so the CPU feature decides and the probe confirms).  0: another libm -- the device keeps its
+// own library for these functions (k_bsdf then matches the reference within the tolerance of tests/test_gpu_parity.py, not bit for bit).
+static int probe_host_libm()
+{
+	static int cached = -1;
+	if (cached >= 0) return cached;
+	bool fma_cpu = false;
+#if defined(__x86_64__)
+	fma_cpu = __builtin_cpu_supports("fma") && __builtin_cpu_supports("avx2");
+#endif
+	auto same = [](float a, float b) { uint32_t x, y; std::memcpy(&x, &a, 4); std::memcpy(&y, &b, 4); return x == y || (a != a && b != b); };
+	auto run = [&](bool fmab) {
+		uint32_t st = 0x2545f491u;
+		auto rnd = [&]() { st = st * 1664525u + 1013904223u; return st; };
+		auto u01 = [&]() { return (float)(rnd() >> 8) * (1.0f / 16777216.0f); };
+		for (int i = 0; i < 200000; i++)
+		{
+			float x, y;
+			switch (i & 3)
+			{
+			case 0: { const uint32_t a = rnd(), b = rnd(); std::memcpy(&x, &a, 4); std::memcpy(&y, &b, 4); break; }   // raw bit patterns: every exponent, specials
+			case 1: x = u01(); y = u01() * 8.f; break;                                                                  // the call sites' ranges
+			case 2: x = (u01() - 0.5f) * 250.f; y = (u01() - 0.5f) * 64.f; break;
+			default: x = u01() * 1e-3f; y = 1.f / (u01() * 100.f + 1.f); break;
+			}
+			const float e = fmab ? jp::lm::expf_libm<true>(x) : jp::lm::expf_libm<false>(x), l = fmab ? jp::lm::logf_libm<true>(x) : jp::lm::logf_libm<false>(x);
+			const float pw = fmab ? jp::lm::powf_libm<true>(x, y) : jp::lm::powf_libm<false>(x, y);
+			if (!same(e, ::expf(x)) || !same(l, ::logf(x)) || !same(pw, ::powf(x, y))) return false;
+			const float a = (i & 3) == 0 ? x : x * 2.f - 1.f;
+			if (!same(jp::lm::acosf_libm(a), ::acosf(a)) || !same(jp::lm::atanf_libm(x), ::atanf(x))) return false;
+			bool ok; const float t = jp::lm::tanf_libm(x * 8.f, &ok);
+			if (ok && !same(t, ::tanf(x * 8.f))) return false;
+		}
+		return true;
+	};
+	int mode = 0;
+	if (run(fma_cpu)) mode = 1 | (fma_cpu ? 2 : 0);
+	else if (run(!fma_cpu)) mode = 1 | (fma_cpu ? 0 : 2);
+	if (const char* e = getenv("JETPBRT_LIBM")) { int v = atoi(e); if (v >= 0 && v <= 3) mode = v; }
+	cached = mode;
+	return cached;
+}
+
 // gamma_encoding of film.h:24 exactly as the host computes it (std::pow on floats = powf, product in double, truncation)
 static inline unsigned char host_gamma_encoding(float x)
 {
@@ -1413,6 +1458,7 @@ const char* jp_last_error(void) { return g_err.c_str(); }
 int jp_gamma_thresholds(float* out255) { if (!out255) return fail(JP_ERR_INVALID_ARGUMENT, "jp_gamma_thresholds: null argument"); std::memcpy(out255, host_gamma_thresholds(), 255 * sizeof(float)); return JP_OK; }
 int jp_abi_version(void) { return JP_ABI_VERSION; }
 int jp_probe_libm_sincosf(void) { return probe_host_sincosf(); }
+int jp_probe_libm_xbsdf(void) { return probe_host_libm(); }
 
 int jp_create_context(int device_id, JpContext** out)
 {
@@ -1434,6 +1480,8 @@ int jp_create_context(int device_id, JpContext** out)
 	{ delete c; return fail(JP_ERR_DEVICE, "jp_create_context: stream/event/counter allocation failed"); }
 	c->sincosf_mode = probe_host_sincosf();
 	{ hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(jp::g_sincosf_mode), &c->sincosf_mode, sizeof(int)); if (e != hipSuccess) { jp_destroy_context(c); return fail(JP_ERR_DEVICE, std::string("jp_create_context: hipMemcpyToSymbol: ") + hipGetErrorString(e)); } }
+	c->libm_mode = probe_host_libm();
+	{ hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(jp::xb::g_libm_mode), &c->libm_mode, sizeof(int)); if (e != hipSuccess) { jp_destroy_context(c); return fail(JP_ERR_DEVICE, std::string("jp_create_context: hipMemcpyToSymbol: ") + hipGetErrorString(e)); } }
 	*out = c;
 	return JP_OK;
 }
@@ -2171,7 +2219,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 		c->q.cap = cap; c->q.R = R;
 		{   // spill area of the walkers' stacks: the words a thread may need beyond the ones kept in LDS
 			const int deep = std::max(c->stack_depth, c->trav_mode == 3 ? (int)(c->lds_bytes_shadow / (JP_BLOCK * sizeof(int))) : 0);
-			const size_t need = c->persist && deep > c->stack_lds_words ? (size_t)(deep - c->stack_lds_words) * G * JP_BLOCK : 1;
+			const size_t need = c->persist && deep >= c->stack_lds_words ? (size_t)(deep - c->stack_lds_words + 1) * G * JP_BLOCK : 1;   // (+1: Walker<4> keeps one LDS word as a dump slot)
 			if (c->spill_words < need) { if (c->d_spill) hipFree(c->d_spill); c->d_spill = nullptr; HIP_TRY(hipMalloc((void**)&c->d_spill, need * sizeof(int))); c->spill_words = need; }
 		}
 		if (c->pix_acc_n < (size_t)npix) { if (c->d_pix_acc) hipFree(c->d_pix_acc); c->d_pix_acc = nullptr; HIP_TRY(hipMalloc((void**)&c->d_pix_acc, (size_t)npix * 16)); c->pix_acc_n = (size_t)npix; }
@@ -2627,7 +2675,7 @@ int jp_get_build_info(JpContext* c, JpBuildInfo* out)
 	out->built_on_device = c->build_on_device ? 1 : 0; out->traversal_mode = c->trav_mode; out->bvh_nodes = c->bvh_nodes; out->bvh_height = c->bvh_height;
 	out->device_build_ms = c->build_ms; out->libm_sincosf = c->sincosf_mode; out->lanes_last_render = c->last_lanes;
 	out->fused_last_render = c->last_fused; out->fused_region = c->last_region; out->fused_workgroups = c->last_wgs;
-	out->q4_nodes = c->use_q4 ? c->sv.n_q4 : 0;
+	out->q4_nodes = c->use_q4 ? c->sv.n_q4 : 0; out->libm_xbsdf = c->libm_mode;
 	return JP_OK;
 }
 

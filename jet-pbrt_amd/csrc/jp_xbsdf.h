@@ -3,11 +3,14 @@
 // TrowbridgeReitzDistribution's full-distribution branch microfacet.cc:326-350, FMicrofacetTransmission bsdf.cc:80-145 (including the
 // world-space FBSDF::Pdf call on local vectors at bsdf.cc:141), FresnelNoOp bsdf.h:664-667 and general FresnelConductor /
 // FresnelDielectric parameters.  No material of material.h instantiates these, so they live outside the render kernels (k_shade's
-// closures are unchanged) and are reached through jp_bsdf / k_bsdf.  Same operation order as the reference; the transcendental
-// functions the reference takes from libm (logf, expf, powf, acosf, atanf, tanf) are the device library's here (1-2 ulp), so the
-// parity bar for these classes is a stated tolerance against the reference's KATs (tests/golden/kat_bsdf.npz), not bit equality.
+// closures are unchanged) and are reached through jp_bsdf / k_bsdf.  Same operation order as the reference.  Round 3: the
+// transcendental functions the reference takes from libm (logf, expf, powf, acosf, atanf, tanf) are glibc's own algorithms in the same
+// IEEE arithmetic (jp_libm.h), selected when jp_create_context finds that they reproduce the host's libm (g_libm_mode): these classes
+// are then bit-exact against the reference's KATs (tests/golden/kat_bsdf.npz) like the closures the materials build; with another libm
+// the device library's functions stay and the stated tolerance applies (tests/test_gpu_parity.py).
 #pragma once
 #include "jp_shading.h"
+#include "jp_libm.h"
 
 namespace jp
 {
@@ -27,6 +30,14 @@ namespace jp
 {
 namespace xb
 {
+// bit 0: jp_libm.h reproduces the host's logf / expf / powf / acosf / atanf / tanf; bit 1: the host runs libm's FMA build of the first three
+__device__ __constant__ int g_libm_mode = 0;
+__device__ __forceinline__ float m_logf(float x) { const int m = g_libm_mode; if (m & 1) return (m & 2) ? lm::logf_libm<true>(x) : lm::logf_libm<false>(x); return logf(x); }
+__device__ __forceinline__ float m_expf(float x) { const int m = g_libm_mode; if (m & 1) return (m & 2) ? lm::expf_libm<true>(x) : lm::expf_libm<false>(x); return expf(x); }
+__device__ __forceinline__ float m_powf(float x, float y) { const int m = g_libm_mode; if (m & 1) return (m & 2) ? lm::powf_libm<true>(x, y) : lm::powf_libm<false>(x, y); return powf(x, y); }
+__device__ __forceinline__ float m_acosf(float x) { return (g_libm_mode & 1) ? lm::acosf_libm(x) : acosf(x); }
+__device__ __forceinline__ float m_atanf(float x) { return (g_libm_mode & 1) ? lm::atanf_libm(x) : atanf(x); }
+__device__ __forceinline__ float m_tanf(float x) { if (g_libm_mode & 1) { bool ok; const float t = lm::tanf_libm(x, &ok); if (ok) return t; } return tanf(x); }
 #define JP_XB_INV2PI (1.0f / (2.0f * JP_PI))                       // pbrt.h:40,45
 struct Dist { int kind; float ax, ay; bool vis; };
 __device__ __forceinline__ float cos2phi(V3 w) { return cosphi(w) * cosphi(w); }                 // bsdf.h:50-52
@@ -37,7 +48,7 @@ __device__ __forceinline__ float ErfInv(float x)                                
 {
 	float w, p;
 	x = clampf(x, -.99999f, .99999f);
-	w = -logf((1 - x) * (1 + x));
+	w = -m_logf((1 - x) * (1 + x));
 	if (w < 5)
 	{
 		w = w - 2.5f;
@@ -59,14 +70,14 @@ __device__ __forceinline__ float Erf(float x)                                   
 	if (x < 0) sign = -1;
 	x = fabsf(x);
 	float t = 1 / (1 + p * x);
-	float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * expf(-x * x);
+	float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * m_expf(-x * x);
 	return sign * y;
 }
 __device__ __forceinline__ void BeckmannSample11(float cosThetaI, float U1, float U2, float* slope_x, float* slope_y)   // microfacet.cc:67-144
 {
 	if (cosThetaI > .9999f)
 	{
-		float r = sqrtf(-logf(1.0f - U1));
+		float r = sqrtf(-m_logf(1.0f - U1));
 		float sinPhi, cosPhi; sincos_f(2 * JP_PI * U2, &sinPhi, &cosPhi);
 		*slope_x = r * cosPhi; *slope_y = r * sinPhi;
 		return;
@@ -75,19 +86,19 @@ __device__ __forceinline__ void BeckmannSample11(float cosThetaI, float U1, floa
 	float tanThetaI = sinThetaI / cosThetaI;
 	float cotThetaI = 1 / tanThetaI;
 	float a = -1, c = Erf(cotThetaI);
-	float sample_x = smax(U1, (float)1e-6f);
-	float thetaI = acosf(cosThetaI);
-	float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
-	float b = c - (1 + c) * powf(1 - sample_x, fit);
-	const float SQRT_PI_INV = 1.f / sqrtf(JP_PI);
-	float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+	float u = smax(U1, (float)1e-6f);
+	float thetaI = m_acosf(cosThetaI);
+	float poly = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+	float b = c - (1 + c) * m_powf(1 - u, poly);
+	const float rsp = 1.f / sqrtf(JP_PI);
+	float nrm = 1 / (1 + c + rsp * tanThetaI * m_expf(-cotThetaI * cotThetaI));
 	int it = 0;
 	while (++it < 10)
 	{
 		if (!(b >= a && b <= c)) b = 0.5f * (a + c);
-		float invErf = ErfInv(b);
-		float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * expf(-invErf * invErf)) - sample_x;
-		float derivative = normalization * (1 - invErf * tanThetaI);
+		float ei = ErfInv(b);
+		float value = nrm * (1 + b + rsp * tanThetaI * m_expf(-ei * ei)) - u;
+		float derivative = nrm * (1 - ei * tanThetaI);
 		if (fabsf(value) < 1e-5f) break;
 		if (value > 0) c = b; else a = b;
 		b -= value / derivative;
@@ -112,7 +123,7 @@ __device__ __forceinline__ float dist_D(const Dist& D, V3 wh)                   
 	if (isinf(tan2Theta)) return 0.;
 	const float cos4Theta = (wh.z * wh.z) * (wh.z * wh.z);
 	if (D.kind == JP_DIST_BECKMANN)
-		return expf(-tan2Theta * (cos2phi(wh) / (D.ax * D.ax) + sin2phi(wh) / (D.ay * D.ay))) / (JP_PI * D.ax * D.ay * cos4Theta);
+		return m_expf(-tan2Theta * (cos2phi(wh) / (D.ax * D.ax) + sin2phi(wh) / (D.ay * D.ay))) / (JP_PI * D.ax * D.ay * cos4Theta);
 	float e = (cos2phi(wh) / (D.ax * D.ax) + sin2phi(wh) / (D.ay * D.ay)) * tan2Theta;
 	return 1 / (JP_PI * D.ax * D.ay * cos4Theta * (1 + e) * (1 + e));
 }
@@ -153,14 +164,14 @@ __device__ __forceinline__ V3 dist_sample_wh(const Dist& D, V3 wo, float u0, flo
 		float tan2Theta, phi;
 		if (D.ax == D.ay)
 		{
-			float logSample = logf(1 - u0);
+			float logSample = m_logf(1 - u0);
 			tan2Theta = -D.ax * D.ax * logSample;
 			phi = u1 * 2 * JP_PI;
 		}
 		else
 		{
-			float logSample = logf(1 - u0);
-			phi = atanf(D.ay / D.ax * tanf(2 * JP_PI * u1 + 0.5f * JP_PI));
+			float logSample = m_logf(1 - u0);
+			phi = m_atanf(D.ay / D.ax * m_tanf(2 * JP_PI * u1 + 0.5f * JP_PI));
 			if (u1 > 0.5f) phi += JP_PI;
 			float sinPhi, cosPhi; sincos_f(phi, &sinPhi, &cosPhi);
 			float ax2 = D.ax * D.ax, ay2 = D.ay * D.ay;
@@ -180,7 +191,7 @@ __device__ __forceinline__ V3 dist_sample_wh(const Dist& D, V3 wo, float u0, flo
 		}
 		else
 		{
-			phi = atanf(D.ay / D.ax * tanf(2 * JP_PI * u1 + .5f * JP_PI));
+			phi = m_atanf(D.ay / D.ax * m_tanf(2 * JP_PI * u1 + .5f * JP_PI));
 			if (u1 > .5f) phi += JP_PI;
 			float sinPhi, cosPhi; sincos_f(phi, &sinPhi, &cosPhi);
 			const float ax2 = D.ax * D.ax, ay2 = D.ay * D.ay;
@@ -231,7 +242,7 @@ __device__ __forceinline__ float x_pdf(const JpBsdfDesc& d, const Frame& fr, V3 
 	{
 		const V3 wr = reflect(wo, mk(0, 0, 1));
 		const float cosTheta = smax((float)0, dot(wr, wi));
-		return (d.exponent + 1) * powf(cosTheta, d.exponent) * JP_XB_INV2PI;
+		return (d.exponent + 1) * m_powf(cosTheta, d.exponent) * JP_XB_INV2PI;
 	}
 	default: return 0;                                                                               // delta BSDFs bsdf.h:410-413, 473-476
 	}
@@ -275,7 +286,7 @@ __device__ __forceinline__ V3 x_eval(const JpBsdfDesc& d, const Frame& fr, V3 wo
 		const V3 wr = reflect(wo, mk(0, 0, 1));
 		const float cos_alpha = dot(wr, wi);
 		const V3 rho = mk(d.color[0], d.color[1], d.color[2]) * (d.exponent + 2.f) * JP_XB_INV2PI;
-		return rho * powf(cos_alpha, d.exponent);
+		return rho * m_powf(cos_alpha, d.exponent);
 	}
 	default: return splat(0);
 	}
@@ -324,7 +335,7 @@ __device__ __forceinline__ BsdfSample x_sample(const JpBsdfDesc& d, const Frame&
 	case JP_BSDF_PHONG:                                                                              // bsdf.h:592-611
 	{
 		const float phi = 2 * JP_PI * ux;
-		const float cos_theta = powf(uy, (float)1 / (d.exponent + 1));
+		const float cos_theta = m_powf(uy, (float)1 / (d.exponent + 1));
 		const float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
 		float sphi, cphi; sincos_f(phi, &sphi, &cphi);
 		V3 wl = mk(cphi * sin_theta, sphi * sin_theta, cos_theta);

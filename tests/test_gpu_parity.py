@@ -34,7 +34,7 @@ def assert_film(gpu_ctx, film, ref, name=None, tol=TOL_L2):
     found or not depending on the tree, the oracle's tree follows libc rand(), the device's is its own.  On the Cornell box that
     is about one sample in 1e7 (seen: 1 pixel of 10,240 at 1024 spp, off by 2.5e-5), so this check allows a pixel in a thousand to
     differ minutely; the reference-tree tests below, where both sides walk the same tree, assert strict equality."""
-    if gpu_ctx.build_info().libm_sincosf != 0 and (name is None or name in EXACT_SCENES):
+    if gpu_ctx.lib.jp_probe_libm_sincosf() != 0 and (name is None or name in EXACT_SCENES):    # (= JpBuildInfo.libm_sincosf, without needing a scene)
         exact = (film == ref).all(-1).mean()
         assert exact >= 0.999 and l2(film, ref) < 1e-6, "film differs from the oracle: mean L2 %.3e, exact px %.5f" % (l2(film, ref), exact)
     else:
@@ -912,16 +912,17 @@ def test_device_tone_map_bytes_equal_the_host_gamma_encoding(H, gpu_ctx, tmp_pat
 def test_reflection_api_by_value_on_the_device(H, gpu_ctx):
     """every BSDF class of the reference by value through jp_bsdf (k_bsdf, jp_xbsdf.h) against the compiled
     reference's KATs (tests/golden/kat_bsdf.npz, 16 BSDFs x 384 shading events: Evalf, Pdf, Sample).
-    Tolerance.  The closures the materials build (Lambert, mirror, Fresnel specular, TrowbridgeReitz visible-area reflection) are the
-    render path's own code: BIT-EXACT when the device reproduces the host libm's sinf/cosf.  The classes no material instantiates call
-    logf / expf / powf / acosf / atanf / tanf, which the reference takes from glibc and the device from its own library (1-2 ulp each,
-    not bit-reproducible), and Beckmann's Newton iteration amplifies that: values within 2e-4 relative (+1e-6 absolute), the sampled
-    direction within 2e-4, flags and the zero / non-zero pattern identical except where the reference value itself is within that
-    tolerance of a branch (counted, < 1 % of the events)."""
+    Round 3: BIT-EXACT for all 16 BSDFs.  The classes no material instantiates call logf / expf / powf / acosf / atanf / tanf; the
+    device runs glibc's own algorithms for them in the same IEEE arithmetic (csrc/jp_libm.h) once jp_create_context has found that
+    they reproduce the host's libm (JpBuildInfo.libm_xbsdf bit 0), as it does for sinf / cosf.  Only with another libm on the host
+    does the round-2 tolerance apply: values within 2e-4 relative (+1e-6 absolute), the sampled direction within 2e-4, flags and the
+    zero / non-zero pattern identical except in < 1 % of the events (Beckmann's Newton iteration amplifies a 1-ulp difference)."""
     g = np.load(os.path.join(H.GOLDEN, "kat_bsdf.npz"))
     nrm, wo, wi, u = H.bsdf_inputs(384, 77)
     exact_kinds = ("lambert", "mirror", "fresnel_specular", "tr_conductor", "tr_noop_aniso")
     libm = gpu_ctx.build_info_any().libm_sincosf if hasattr(gpu_ctx, "build_info_any") else H.jp.hip_lib().jp_probe_libm_sincosf()
+    libm_x = H.jp.hip_lib().jp_probe_libm_xbsdf() & 1
+    assert libm != 0 and libm_x == 1, "this image's glibc 2.35 must be reproduced (tests/test_libm_exact.py)"
     for name, desc in H.bsdf_cases().items():
         r = gpu_ctx.bsdf(desc, nrm, wo, wi, u)
         bad_events = np.zeros(384, bool)
@@ -930,7 +931,7 @@ def test_reflection_api_by_value_on_the_device(H, gpu_ctx):
             if k == "sflags":
                 bad_events |= got != want
                 continue
-            if name in exact_kinds and libm != 0:
+            if libm != 0 and (name in exact_kinds or libm_x):
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%s.%s not bit-exact: %d differ" % (name, k, int((got != want).sum()))
                 continue
             tol = 2e-4 * np.abs(want) + (2e-4 if k == "swi" else 1e-6)

@@ -284,8 +284,11 @@ def test_kernel_register_budgets(H, tmp_path):
     assert len(rows) > 40
     for name in ("k_shade<true, true, true, true>", "k_shade<true, true, true, false>", "k_shade<true, false, true, true>"):
         assert rows[name]["vgpr"] <= 168 and rows[name]["waves"] >= 3 and rows[name]["scratch"] == 0, (name, rows[name])
-    for name in ("k_extend<2>", "k_extend<0>", "k_extend_persist<0, 16, true>", "k_shadow_persist<3, 16, true>", "k_extend_persist<5, 16, false>"):
+    for name in ("k_extend<2>", "k_extend<0>", "k_extend_persist<0, 16, true>", "k_shadow_persist<3, 16, true>", "k_extend_persist<5, 16, false>",
+                 "k_extend_persist<4, 16, true>", "k_shadow_persist<4, 16, true>"):
         assert rows[name]["vgpr"] <= 64 and rows[name]["waves"] == 8 and rows[name]["scratch"] == 0, (name, rows[name])
     assert rows["k_shadow<2>"]["waves"] >= 6
-    spills = [n for n, r in rows.items() if r["scratch"] and not n.startswith(("k_other", "k_wide_level"))]
+    # (k_path, the opt-in fused schedule: register allocation aimed at 3 waves per SIMD, a few phase-level values spill outside its inner loops)
+    assert all(r["waves"] >= 3 for n, r in rows.items() if n.startswith("k_path"))
+    spills = [n for n, r in rows.items() if r["scratch"] and not n.startswith(("k_other", "k_wide_level", "k_path"))]
     assert not spills, spills
