@@ -21,8 +21,11 @@ grows with N (spp = --spp * N), every GPU traces as many paths as in the 1-GPU r
 Rank 0 prints one JSON line.  Besides the contract fields:
   roofline     : dominant kernel class, algorithmic bytes per launch / HIP-event launch duration (events on the kernel
                  stream, taken on the last step of the timed region) vs 8 TB/s HBM; `traffic` = rocprofv3 PMC bytes per unit
-                 (profiles/traffic_r02.json, source named in `traffic_source`) x this run's units per launch; `valu` = the
-                 vector-instruction issue roofline next to it (instructions per unit from the SQ counter passes under profiles/)
+                 (profiles/traffic_r03.json, named once in `notes`) x this run's units per launch; `attributed` = the same launch by
+                 the bytes that kernel class itself moves; `alone` = every class with the GPU to itself: contract / attributed HBM
+                 fraction and the vector-instruction issue fraction (instructions per unit from the SQ counter passes under profiles/)
+  config.sub   : one compact summary per single-GPU BASELINE.json config (value, ms, whole-path fraction, parity, CPU reference);
+                 the full sub-records follow under `configs`
   cpu_baseline : the unmodified reference (oracle/_ref) -- or the oracle port where that library is absent -- timed on this
                  box's host cores on a bounded sample, at 16 threads (main.cc:156) and at min(cores, bands)
   l2_vs_cpu_ref: parity sample.  Cornell: whole 20-row bands at the full spp against the oracle.  Bunny: the whole film at the
@@ -39,7 +42,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0    # wave64 instructions/ns: 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles at 2.4 GHz
+VALU_CLOCK_GHZ = 2.2             # shader clock this workload sustains (profiles/r02g_clocks_power.txt: 2.17-2.24 GHz at 1.15-1.28 kW; 2.4 GHz idle)
+VALU_PEAK_GINST = 256 * 4 * VALU_CLOCK_GHZ / 2.0    # wave64 instructions/ns: 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles
 # algorithmic bytes per unit, SURVEY.md section 8d records attributed to the kernel that moves them (DESIGN.md "Roofline")
 B_EXTEND_PER_RAY = 32 + 8                     # ray read + hit record write
 B_SHADE_PER_PATH_IN = 8 + 40                  # hit record read + path state read
@@ -70,69 +74,82 @@ def build_scene(scenes, backend, key, W, H):
 
 def load_profile_constants():
     """rocprofv3 figures measured in an earlier profiling run and committed under profiles/ (never measured inside this run)"""
-    p = os.path.join(REPO, "profiles", "traffic_r02.json")
-    try:
-        return json.load(open(p))
-    except Exception:
-        return {}
+    for name in ("traffic_r03.json", "traffic_r02.json"):
+        try:
+            d = json.load(open(os.path.join(REPO, "profiles", name)))
+            d["_file"] = "profiles/" + name
+            return d
+        except Exception:
+            continue
+    return {}
+
+
+def r4(x):
+    return float("%.4g" % x)
 
 
 def roofline_record(c, c1, value, spp_total, n, lanes, scene_key, prof):
     """roofline of the dominant kernel class from the per-launch HIP events of one profiled step (counters c), plus the same
-    kernels with the GPU to themselves (c1: one extra step on ONE stream lane) and the whole-path figure"""
+    kernels with the GPU to themselves (c1: one extra step on ONE stream lane) and the whole-path figure.  Every class carries two
+    byte counts: `contract` = SURVEY.md section 8d's per-unit figure (160 B per segment / 96 B per shadow ray: the whole record set,
+    whichever kernel moves it) x units, and `attributed` = the bytes that class itself reads and writes."""
     survivors = max(0, c.closest_rays - c.samples)     # rays written by k_shade (every ray but the camera rays)
-    # (ms, launches, algorithmic bytes = SURVEY.md section 8d per-unit figure x units the class processes, units,
-    #  bytes attributed to the kernel that actually moves each record -- DESIGN.md section 6)
-    cls = {
-        "k_extend": (c.extend_ms, c.extend_launches, B_PER_SEGMENT * c.closest_rays, c.closest_rays, B_EXTEND_PER_RAY * c.closest_rays),
-        "k_shade": (c.shade_ms, c.shade_launches, B_PER_SEGMENT * c.closest_rays, c.closest_rays,
-                    B_SHADE_PER_PATH_IN * c.closest_rays + B_SHADE_PER_SURVIVOR * survivors + B_SHADE_PER_SHADOW_RAY * c.shadow_rays),
-        "k_shadow": (c.shadow_ms, c.shadow_launches, B_PER_SHADOW * c.shadow_rays, c.shadow_rays, B_SHADOW_PER_RAY * c.shadow_rays),
-    }
+
+    def classes(x):
+        sv = max(0, x.closest_rays - x.samples)
+        d = {
+            "k_extend": (x.extend_ms, x.extend_launches, B_PER_SEGMENT * x.closest_rays, x.closest_rays, B_EXTEND_PER_RAY * x.closest_rays),
+            "k_shade": (x.shade_ms, x.shade_launches, B_PER_SEGMENT * x.closest_rays, x.closest_rays,
+                        B_SHADE_PER_PATH_IN * x.closest_rays + B_SHADE_PER_SURVIVOR * sv + B_SHADE_PER_SHADOW_RAY * x.shadow_rays),
+            "k_shadow": (x.shadow_ms, x.shadow_launches, B_PER_SHADOW * x.shadow_rays, x.shadow_rays, B_SHADOW_PER_RAY * x.shadow_rays),
+        }
+        whole = B_PER_SEGMENT * x.closest_rays + B_PER_SHADOW * x.shadow_rays
+        if x.path_launches:                              # fused schedule: ONE kernel moves the whole record set
+            d = {"k_path": (x.path_ms, x.path_launches, whole, x.samples, whole)}
+        return d
+
+    cls = classes(c)
     dom = max(cls, key=lambda k: cls[k][0])
     ms, launches, nbytes, units, attributed = cls[dom]
     launches = max(1, launches)
     achieved = (nbytes / launches) / (ms / launches * 1e-3) / 1e9 if ms > 0 else 0.0
+    att_achieved = (attributed / launches) / (ms / launches * 1e-3) / 1e9 if ms > 0 else 0.0
     bytes_per_sample = (B_PER_SEGMENT * c.closest_rays + B_PER_SHADOW * c.shadow_rays) / max(1, c.samples) + B_FILM_PER_PIXEL / spp_total
-    pk = (prof.get(scene_key) or {}).get(dom) or {}
+    ps = prof.get(scene_key) or {}
+    pk = ps.get(dom) or {}
     traffic = int(pk["hbm_bytes_per_unit"] * units / launches) if "hbm_bytes_per_unit" in pk else None
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": (pk.get("source") if traffic is not None else None),
-            "launch_ms_avg": round(ms / launches, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(nbytes / launches),
-            "unit_bytes": B_PER_SHADOW if dom == "k_shadow" else B_PER_SEGMENT, "units_per_launch": int(units / launches),
-            "attributed_bytes_per_launch": int(attributed / launches),
-            "class_ms": {k: round(v[0], 3) for k, v in cls.items()},
+            "launch_ms_avg": r4(ms / launches), "launches": int(launches), "algorithmic_bytes_per_launch": int(nbytes / launches),
+            "unit_bytes": (B_PER_SHADOW if dom == "k_shadow" else (round(bytes_per_sample, 1) if dom == "k_path" else B_PER_SEGMENT)), "units_per_launch": int(units / launches),
+            "attributed": {"bytes_per_launch": int(attributed / launches), "achieved": round(att_achieved, 1), "frac": round(att_achieved / HBM_PEAK_GBS, 4)},
+            "class_ms": {k: round(v[0], 2) for k, v in cls.items()},
             # several stream lanes: the lanes' kernels overlap, so a launch's duration includes the time it shares the
             # GPU with the other lanes' kernels; kernel_time_over_wall is the average number of kernels in flight
-            "lanes": lanes, "kernel_time_over_wall": round((c.extend_ms + c.shade_ms + c.shadow_ms + c.other_ms) / max(1e-9, c.render_ms), 3),
-            "exclusive": None, "valu": None,
+            "lanes": lanes, "kernel_time_over_wall": round((c.extend_ms + c.shade_ms + c.shadow_ms + c.path_ms + c.other_ms) / max(1e-9, c.render_ms), 2),
             "whole_path": {"bytes_per_sample": round(bytes_per_sample, 1), "segments_per_sample": round(c.closest_rays / max(1, c.samples), 3),
                            "shadow_rays_per_sample": round(c.shadow_rays / max(1, c.samples), 3),
                            "achieved_GBps": round(value * 1e6 * bytes_per_sample / 1e9, 1),
                            "frac": round(value * 1e6 * bytes_per_sample / 1e9 / (HBM_PEAK_GBS * n), 4)}}
-    # vector-instruction issue roofline: wave64 VALU instructions per unit (rocprofv3 SQ_INSTS_VALU, profiles/) x units / time
+    # per class with the GPU to itself (one stream lane): contract and attributed HBM fractions, PMC bytes per unit, and the
+    # vector-instruction issue roofline (wave64 VALU instructions per unit from the SQ counter pass x units / time)
     src = c1 if c1 is not None else c
-    ms1 = {"k_extend": src.extend_ms, "k_shade": src.shade_ms, "k_shadow": src.shadow_ms}
-    n1 = {"k_extend": src.extend_launches, "k_shade": src.shade_launches, "k_shadow": src.shadow_launches}
-    u1 = {"k_extend": src.closest_rays, "k_shade": src.closest_rays, "k_shadow": src.shadow_rays}
-    valu = {}
-    for k in ("k_extend", "k_shade", "k_shadow"):
-        pv = (prof.get(scene_key) or {}).get(k) or {}
-        if "valu_insts_per_unit" in pv and ms1[k] > 0:
-            g = pv["valu_insts_per_unit"] * u1[k] / (ms1[k] * 1e-3) / 1e9          # wave64 instructions per ns, chip-wide
-            valu[k] = {"wave_insts_per_unit": pv["valu_insts_per_unit"], "achieved_Ginst_s": round(g, 1), "peak_Ginst_s": VALU_PEAK_GINST,
-                       "frac": round(g / VALU_PEAK_GINST, 3), "lane_utilisation": pv.get("lane_utilisation"), "source": pv.get("valu_source")}
-    if valu:
-        roof["valu"] = {"note": "wave64 VALU instructions issued per second vs 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles; kernels alone on the GPU (one stream lane); under this load the shader clock sits at about 2.2 GHz (profiles/r02g_clocks_power.txt), so the peak is 8-9 % generous" if c1 is not None else "from the timed configuration", "kernels": valu}
-    if c1 is not None:
-        units1 = {"k_extend": B_PER_SEGMENT * c1.closest_rays, "k_shade": B_PER_SEGMENT * c1.closest_rays, "k_shadow": B_PER_SHADOW * c1.shadow_rays}
-        dom1 = max(ms1, key=lambda k: ms1[k])
-        excl = {}
-        for k in ("k_extend", "k_shade", "k_shadow"):
-            a1 = units1[k] / max(1e-9, ms1[k] * 1e-3) / 1e9
-            excl[k] = {"launch_ms_avg": round(ms1[k] / max(1, n1[k]), 4), "launches": int(n1[k]), "achieved": round(a1, 1), "frac": round(a1 / HBM_PEAK_GBS, 4)}
-        roof["exclusive"] = {"lanes": 1, "dominant": dom1, "kernels": excl}
+    alone = {}
+    for k, (ms1, n1, nb1, u1, at1) in classes(src).items():
+        if ms1 <= 0:
+            continue
+        e = {"ms": r4(ms1 / max(1, n1)), "frac": round(nb1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 3), "attributed_frac": round(at1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
+        pv = ps.get(k) or {}
+        if "hbm_bytes_per_unit" in pv:
+            e["pmc_bytes_per_unit"] = pv["hbm_bytes_per_unit"]
+        if "valu_insts_per_unit" in pv:
+            g = pv["valu_insts_per_unit"] * u1 / (ms1 * 1e-3) / 1e9
+            e["valu_frac"] = round(g / VALU_PEAK_GINST, 3); e["lane_util"] = pv.get("lane_utilisation")
+        alone[k] = e
+    roof["alone" if c1 is not None else "per_class"] = alone
+    roof["notes"] = {"alone": "one extra untimed step on ONE stream lane: every kernel has the GPU to itself" if c1 is not None else "from the timed configuration",
+                     "valu_peak": "256 CUs x 4 SIMDs x %.1f GHz / 2 cycles = %.0f G wave64 instructions/s" % (VALU_CLOCK_GHZ, VALU_PEAK_GINST),
+                     "pmc": "%s: rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE and SQ_INSTS_VALU per unit, measured in an earlier profiling run of this scene" % prof.get("_file", "-")}
     return roof
 
 
@@ -151,7 +168,7 @@ def main():
     ap.add_argument("--configs", default="1,2,3", help="sub-records at N = 1: comma list of BASELINE.json config indices, '' for none")
     ap.add_argument("--min-seconds", type=float, default=10.0, help="length of each sub-record's timed region")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity samples")
-    ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-lane step behind roofline.exclusive (profiling runs: keeps rocprofv3's per-kernel averages to the timed configuration)")
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-lane step behind roofline.alone (profiling runs: keeps rocprofv3's per-kernel averages to the timed configuration)")
     ap.add_argument("--band-rows", type=int, default=0, help="band height for sharding / lanes (0: largest height <= 20 that deals evenly)")
     ap.add_argument("--cpu-bands", type=int, default=2, help="20-row bands rendered by the CPU oracle at the full spp (Cornell parity sample)")
     args = ap.parse_args()
@@ -211,12 +228,11 @@ def main():
             if world == 1:
                 return ctx.render(params)                      # jp_render: kernels + film download, blocking
             ctx.render_device(params, film_dev.data_ptr(), sync=True)
-            if backend == "nccl":
-                dist.reduce(film_dev, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI onto rank 0's film
-                return film_dev.cpu().numpy() if rank == 0 else None
-            host = film_dev.cpu()                              # rehearsal backend: the same reduce on host tensors
-            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-            return host.numpy() if rank == 0 else None
+            if backend == "nccl":                              # RCCL over xGMI: every rank sends its own rows, packed (1/N of the film)
+                full = jp.distributed.assemble_bands(film_dev, H, band_rows, dist)
+                return full.cpu().numpy() if rank == 0 else None
+            full = jp.distributed.assemble_bands(film_dev.cpu(), H, band_rows, dist)   # rehearsal backend: the same on host tensors
+            return full.numpy() if rank == 0 else None
 
         ctx.set_profiling(False)
         for _ in range(warmup):
@@ -247,7 +263,7 @@ def main():
         lanes = int(bi.lanes_last_render)
         # With several lanes a launch shares the GPU with the other lanes' kernels, so its duration (and the per-launch roofline
         # figure the contract asks for) reflects that sharing.  One extra, untimed step on ONE lane gives the same kernels' figures
-        # when each has the GPU to itself -- reported next to the contract figure as roofline.exclusive.
+        # when each has the GPU to itself -- reported next to the contract figure as roofline.alone.
         c1 = None
         if lanes > 1 and "JETPBRT_LANES" not in os.environ and not args.no_exclusive:
             os.environ["JETPBRT_LANES"] = "1"
@@ -308,14 +324,20 @@ def main():
                 ref = rctx.render(jp.render_params(W, H, spp_total, 5, 1234))
                 t_ref_gpu = time.perf_counter() - t1
                 b = 17 if nbands > 17 else nbands // 2
-                low = 8
-                pb = jp.render_params(W, H, low, 5, 1234, band_rows=20, shard_index=b, shard_count=nbands)
+                # the link to the CPU oracle: rows spread over the whole image (2-row bands j with j % 30 == 8: ten tasks for ten
+                # oracle threads) at 192 spp, strictly compared
+                low = min(192, spp_total)
+                pb = jp.render_params(W, H, low, 5, 1234, band_rows=2, shard_index=8, shard_count=30)
                 gband = rctx.render(pb)
                 Hn.libc_srand(1)                            # the reference process' rand() state when it builds its tree
+                t1 = time.perf_counter()
                 oband, _ = Hn.oracle_render(rscene, pb, tb)
-                y0, y1 = b * 20, min(H, b * 20 + 20)
-                link = bool(np.array_equal(gband[y0:y1].view(np.uint32), oband[y0:y1].view(np.uint32)))
-                link_l2 = float(np.sqrt(((gband[y0:y1] - oband[y0:y1]) ** 2).sum(-1)).mean())
+                t_link = time.perf_counter() - t1
+                lrows = np.zeros(H, bool)
+                for y0, y1 in jp.distributed.bands_of(H, 8, 30, 2):
+                    lrows[y0:y1] = True
+                link = bool(np.array_equal(gband[lrows].view(np.uint32), oband[lrows].view(np.uint32)))
+                link_l2 = float(np.sqrt(((gband[lrows] - oband[lrows]) ** 2).sum(-1)).mean())
             finally:
                 rctx.close()
             d = np.sqrt(((film - ref) ** 2).sum(-1))
@@ -323,7 +345,7 @@ def main():
             parity = {"mean_per_pixel_l2": float(d.mean()), "max_per_pixel_l2": float(d.max()), "pixels": int(d.size), "spp": spp_total,
                       "tolerance": 1e-4,
                       "reference": "device reference-tree mode (traversal mode 5: the reference's rand()-driven tree, its box test and order) at the full size, %.1f s" % t_ref_gpu,
-                      "reference_vs_oracle": {"sample": "band %d of %d at %d spp, oracle/pt_oracle.cc on the CPU" % (b, nbands, low), "bit_identical": link, "mean_per_pixel_l2": link_l2},
+                      "reference_vs_oracle": {"sample": "%d rows spread over the image (2-row bands j %% 30 == 8) at %d spp, oracle/pt_oracle.cc on the CPU, %.1f s" % (int(lrows.sum()), low, t_link), "bit_identical": link, "mean_per_pixel_l2": link_l2},
                       "fraction_pixels_identical": float((film == ref).all(-1).mean()), "fraction_pixels_gt_1e-3": float((d > 1e-3).mean()),
                       "band_through_meshes": {"band": b, "mean_per_pixel_l2": float(band.mean()), "fraction_pixels_identical": float((film[b * 20:b * 20 + 20] == ref[b * 20:b * 20 + 20]).all(-1).mean())},
                       "note": "the default path walks its own SAH tree: ~3e-4 of the samples through the meshes find a different first hit than the reference's rand()-driven tree does (fringe hits, DESIGN.md Numerics)",
@@ -384,13 +406,19 @@ def main():
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": args.scaling if n > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": head["workload"],
-                       "parallelism": ("%d-row band shard x%d + RCCL film reduce" % (band_rows, n) if n > 1 else "single GPU") + ", %d stream lanes per GPU" % lanes},
+                       "parallelism": ("%d-row band shard x%d + RCCL gather of the ranks' rows" % (band_rows, n) if n > 1 else "single GPU") + ", %d stream lanes per GPU" % lanes},
             "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"], "l2_vs_cpu_ref": head["l2_vs_cpu_ref"],
             "timed_region_s": head["timed_region_s"],
         }
         if subs:
+            out["config"]["sub"] = {k.replace("configs[", "c").replace("]", ""): {
+                "Msamples_s": v["value"], "ms": v["ms_per_step"], "frames": v["steps"], "s": v["timed_region_s"], "whole_path_frac": v["roofline"]["whole_path"]["frac"],
+                "dominant": v["roofline"]["kernel"], "frac": v["roofline"]["frac"],
+                "l2": (None if not v.get("l2_vs_cpu_ref") else r4(v["l2_vs_cpu_ref"]["mean_per_pixel_l2"])),
+                "identical": (None if not v.get("l2_vs_cpu_ref") else (v["l2_vs_cpu_ref"].get("bit_identical") if "bit_identical" in v["l2_vs_cpu_ref"] else round(v["l2_vs_cpu_ref"].get("fraction_pixels_identical", 0), 4))),
+                "cpu_ref_Msamples_s": (None if not v.get("cpu_baseline") else v["cpu_baseline"]["value"])} for k, v in subs.items()}
             out["configs"] = subs
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out, separators=(",", ":")), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

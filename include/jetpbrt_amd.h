@@ -192,6 +192,10 @@ int  jp_render_device(JpContext* ctx, const JpRenderParams* params, void* film_r
  * [0, 1]) and the device counts the thresholds <= x (jp_gamma_thresholds: that table, for tests). */
 int  jp_render_rgb8(JpContext* ctx, const JpRenderParams* params, uint8_t* rgb8_host, float* film_rgb_host);
 int  jp_gamma_thresholds(float* out255);
+/* test hook (pure host code): every fp32 value of [0, 1] -- 1,065,353,217 bit patterns, n_threads host threads -- through the host's
+ * gamma_encoding and through the threshold table; returns the number of values whose bytes differ (0: the device tone map is
+ * byte-identical for EVERY input; the table's binary search assumes the host's powf-based curve never steps down) */
+long long jp_gamma_sweep(int n_threads);
 int  jp_synchronize(JpContext* ctx);
 
 /* per-kernel-class event timing (adds two events per launch); off by default */

@@ -28,6 +28,8 @@
 #include <vector>
 #include <algorithm>
 #include <cmath>
+#include <mutex>
+#include <thread>
 #include "jp_lbvh.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1310,6 +1312,7 @@ struct JpContext
 	int stack_lds_words = 12;
 	int* d_spill = nullptr; size_t spill_words = 0;
 	float* d_film = nullptr; size_t film_n = 0;
+	float *d_bsdf_in = nullptr, *d_bsdf_out = nullptr; int* d_bsdf_fl = nullptr; size_t bsdf_cap = 0;   // jp_bsdf scratch
 	float* d_gamma = nullptr; unsigned char* d_rgb8 = nullptr; size_t rgb8_n = 0; unsigned char* h_rgb8 = nullptr; size_t h_rgb8_n = 0;   // jp_render_rgb8
 	float* h_film = nullptr; size_t h_film_n = 0;                // pinned staging buffer of jp_render (a pageable copy of the film costs ~2 ms)
 	DevCounters* d_cnt = nullptr;
@@ -1438,18 +1441,45 @@ static inline unsigned char host_gamma_encoding(float x)
 // their bit patterns and the encoding is non-decreasing, so each threshold is a binary search over 0 .. 0x3f800000
 static const float* host_gamma_thresholds()
 {
-	static float thr[255]; static bool done = false;
-	if (!done)
-	{
+	static float thr[255]; static std::once_flag once;
+	std::call_once(once, []() {
 		for (int k = 1; k <= 255; k++)
 		{
 			uint32_t lo = 0, hi = 0x3f800000u;                       // enc(lo) < k (enc(0) = 0) ... enc(hi) >= k (enc(1) = 255)
 			while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; float f; std::memcpy(&f, &mid, 4); if (host_gamma_encoding(f) >= k) hi = mid; else lo = mid; }
 			std::memcpy(&thr[k - 1], &hi, 4);
 		}
-		done = true;
-	}
+	});
 	return thr;
+}
+// The binary search above assumes that the host's powf-based encoding never steps DOWN on [0, 1] (powf is accurate to under an ulp, not
+// guaranteed monotone).  This sweeps EVERY float bit pattern of [0, 1] -- 1,065,353,217 values, n_threads host threads -- and counts
+// the values whose byte differs from (number of thresholds <= x): 0 means the device tone map is byte-identical to gamma_encoding for
+// every input (tests/test_host_and_abi.py).
+static unsigned long long host_gamma_sweep(int n_threads)
+{
+	const float* thr = host_gamma_thresholds();
+	n_threads = std::max(1, std::min(64, n_threads));
+	std::vector<unsigned long long> bad((size_t)n_threads, 0ull);
+	std::vector<std::thread> pool;
+	const uint64_t total = 0x3f800000ull + 1;
+	for (int t = 0; t < n_threads; t++)
+		pool.emplace_back([&, t]() {
+			const uint64_t a = total * t / n_threads, b = total * (t + 1) / n_threads;
+			int k = 0;                                                    // thresholds <= x: x ascends, so k only grows
+			{ const uint32_t u = (uint32_t)a; float f; std::memcpy(&f, &u, 4); while (k < 255 && thr[k] <= f) k++; }
+			unsigned long long nb = 0;
+			for (uint64_t i = a; i < b; i++)
+			{
+				const uint32_t u = (uint32_t)i; float f; std::memcpy(&f, &u, 4);
+				while (k < 255 && thr[k] <= f) k++;
+				if (host_gamma_encoding(f) != (unsigned char)k) nb++;
+			}
+			bad[(size_t)t] = nb;
+		});
+	for (auto& th : pool) th.join();
+	unsigned long long s2 = 0; for (unsigned long long v : bad) s2 += v;
+	return s2;
 }
 
 extern "C" {
@@ -1457,6 +1487,7 @@ extern "C" {
 const char* jp_last_error(void) { return g_err.c_str(); }
 int jp_gamma_thresholds(float* out255) { if (!out255) return fail(JP_ERR_INVALID_ARGUMENT, "jp_gamma_thresholds: null argument"); std::memcpy(out255, host_gamma_thresholds(), 255 * sizeof(float)); return JP_OK; }
 int jp_abi_version(void) { return JP_ABI_VERSION; }
+long long jp_gamma_sweep(int n_threads) { return (long long)host_gamma_sweep(n_threads); }
 int jp_probe_libm_sincosf(void) { return probe_host_sincosf(); }
 int jp_probe_libm_xbsdf(void) { return probe_host_libm(); }
 
@@ -1501,6 +1532,7 @@ int jp_destroy_context(JpContext* c)
 	if (c->d_spill) hipFree(c->d_spill);
 	if (c->d_film) hipFree(c->d_film);
 	if (c->h_film) hipHostFree(c->h_film);
+	if (c->d_bsdf_in) hipFree(c->d_bsdf_in); if (c->d_bsdf_out) hipFree(c->d_bsdf_out); if (c->d_bsdf_fl) hipFree(c->d_bsdf_fl);
 	if (c->d_gamma) hipFree(c->d_gamma);
 	if (c->d_rgb8) hipFree(c->d_rgb8);
 	if (c->h_rgb8) hipHostFree(c->h_rgb8);
@@ -2196,26 +2228,35 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 		// what it does with 2^24)
 		const int slot_bits = c->n_planes <= 31 ? 27 : 24;
 		const unsigned int PMAX = slot_bits == 27 ? (1u << 26) : (1u << 24);
-		// memory budget for the queues: ~ (120 + 32 * planes) bytes per slot
+		// memory budget for the queues: ~ (136 + 32 * planes) bytes per slot.  ONE budget -- half of what is free, at most 24 GB per lane --
+		// shared by the lanes that render concurrently (each lane sizes its own queue set from its share), and when the allocation still
+		// fails (another process took the memory in between) the batch is halved and tried again before the call gives up
 		size_t freeB = 0, totalB = 0; hipMemGetInfo(&freeB, &totalB);
-		size_t per = 136 + 32 * (size_t)c->n_planes;
-		size_t budget = std::min<size_t>((size_t)24 << 30, (freeB + (c->cap ? (size_t)c->cap * (136 + 32 * (size_t)c->planes_alloc) : 0)) / 2);
+		const size_t per = 136 + 32 * (size_t)c->n_planes;
+		size_t budget = std::min<size_t>((size_t)24 << 30, (freeB / (size_t)std::max(1, lane_count) + (c->cap ? (size_t)c->cap * (136 + 32 * (size_t)c->planes_alloc) : 0)) / 2);
 		if (const char* e = getenv("JETPBRT_MAX_SLOTS")) { long long v = atoll(e); if (v > 0) budget = std::min<size_t>(budget, (size_t)v * per); }
-		unsigned int pcap = (unsigned int)std::min<size_t>(PMAX, std::max<size_t>((size_t)npix, budget / per));
-		int sbatch = (int)std::max<long long>(1, std::min<long long>(rp->spp, pcap / npix));
-		{   // equal batches: ceil(spp / sbatch) batches of (nearly) the same size instead of full ones and a remainder (1024 spp in batches of
-			// 192 would end with a 64-spp batch whose launches fill a third of the GPU)
-			const int nb = (rp->spp + sbatch - 1) / sbatch;
-			sbatch = (rp->spp + nb - 1) / nb;
+		int sbatch = 1; unsigned int P = 0, G = 1, R = JP_BLOCK, cap = 0;
+		for (int attempt = 0;; attempt++)
+		{
+			const unsigned int pcap = (unsigned int)std::min<size_t>(PMAX, std::max<size_t>((size_t)npix, budget / per));
+			sbatch = (int)std::max<long long>(1, std::min<long long>(rp->spp, pcap / npix));
+			{   // equal batches: ceil(spp / sbatch) batches of (nearly) the same size instead of full ones and a remainder (1024 spp in batches of
+				// 192 would end with a 64-spp batch whose launches fill a third of the GPU)
+				const int nb = (rp->spp + sbatch - 1) / sbatch;
+				sbatch = (rp->spp + nb - 1) / nb;
+			}
+			if ((long long)sbatch * npix > (long long)PMAX) return fail(JP_ERR_UNSUPPORTED, "jp_render: shard too large for one batch");
+			P = (unsigned int)((long long)sbatch * npix);
+			const unsigned int nchunks = (P + JP_BLOCK - 1) / JP_BLOCK;
+			G = std::max(1u, std::min(nchunks, (unsigned int)(c->n_cus * c->blocks_per_cu)));   // one region per workgroup
+			G = std::max(G, (nchunks + JP_SHADE_TILE / JP_BLOCK - 1) / (JP_SHADE_TILE / JP_BLOCK));   // R <= JP_SHADE_TILE: k_shade partitions a whole region in LDS and counts its fills in 16 bits
+			R = ((nchunks + G - 1) / G) * JP_BLOCK;
+			cap = G * R;
+			const int st = ensure_queues(c, cap, c->n_planes, G);
+			if (st == JP_OK) break;
+			if (sbatch <= 1 || attempt >= 6) return st;                 // one sample per pixel does not fit either: out of device memory
+			budget = (size_t)sbatch / 2 * (size_t)npix * per;              // half the batch
 		}
-		if ((long long)sbatch * npix > (long long)PMAX) return fail(JP_ERR_UNSUPPORTED, "jp_render: shard too large for one batch");
-		const unsigned int P = (unsigned int)((long long)sbatch * npix);
-		const unsigned int nchunks = (P + JP_BLOCK - 1) / JP_BLOCK;
-		unsigned int G = std::max(1u, std::min(nchunks, (unsigned int)(c->n_cus * c->blocks_per_cu)));   // one region per workgroup
-		G = std::max(G, (nchunks + JP_SHADE_TILE / JP_BLOCK - 1) / (JP_SHADE_TILE / JP_BLOCK));   // R <= JP_SHADE_TILE: k_shade partitions a whole region in LDS and counts its fills in 16 bits
-		const unsigned int R = ((nchunks + G - 1) / G) * JP_BLOCK;
-		const unsigned int cap = G * R;
-		int st = ensure_queues(c, cap, c->n_planes, G); if (st != JP_OK) return st;
 		c->q.cap = cap; c->q.R = R;
 		{   // spill area of the walkers' stacks: the words a thread may need beyond the ones kept in LDS
 			const int deep = std::max(c->stack_depth, c->trav_mode == 3 ? (int)(c->lds_bytes_shadow / (JP_BLOCK * sizeof(int))) : 0);
@@ -2690,26 +2731,30 @@ int jp_bsdf(JpContext* c, const JpBsdfDesc* d, int32_t n, const float* normal, c
 	if (d->kind == JP_BSDF_FRESNEL_SPECULAR && d->eta_a != 1.0f) return fail(JP_ERR_UNSUPPORTED, "jp_bsdf: FFresnelSpecular is implemented for etaI = 1 (FGlassMaterial, material.h:72-75)");
 	if (n == 0) return JP_OK;
 	HIP_TRY(hipSetDevice(c->device));
-	float* din = nullptr; float* dout = nullptr; int* dfl = nullptr;
-	int rc = JP_OK;
-	do
+	// scratch buffers kept in the context (a host FBSDF::Evalf is one event per call: no allocation per event); every copy checked
+	if (c->bsdf_cap < (size_t)n)
 	{
-		if (hipMalloc((void**)&din, (size_t)n * 11 * 4) != hipSuccess || hipMalloc((void**)&dout, (size_t)n * 11 * 4) != hipSuccess || hipMalloc((void**)&dfl, (size_t)n * 4) != hipSuccess)
-		{ rc = fail(JP_ERR_DEVICE, "jp_bsdf: out of device memory"); break; }
-		float *dn = din, *dwo = din + 3 * (size_t)n, *dwi = din + 6 * (size_t)n, *du = din + 9 * (size_t)n;
-		float *df = dout, *dpe = dout + 3 * (size_t)n, *dsf = dout + 4 * (size_t)n, *dswi = dout + 7 * (size_t)n, *dsp = dout + 10 * (size_t)n;
-		hipMemcpyAsync(dn, normal, (size_t)n * 12, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(dwo, wo, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
-		hipMemcpyAsync(dwi, wi, (size_t)n * 12, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(du, u, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
-		const int grid = std::min(c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK);
-		hipLaunchKernelGGL(k_bsdf, dim3(grid), dim3(JP_BLOCK), 0, c->stream, *d, n, (const float*)dn, (const float*)dwo, (const float*)dwi, (const float*)du, df, dpe, dsf, dswi, dsp, dfl);
-		hipMemcpyAsync(f_eval, df, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream); hipMemcpyAsync(pdf_eval, dpe, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
-		hipMemcpyAsync(s_f, dsf, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream); hipMemcpyAsync(s_wi, dswi, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream);
-		hipMemcpyAsync(s_pdf, dsp, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream); hipMemcpyAsync(s_flags, dfl, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
-		hipError_t e = hipStreamSynchronize(c->stream);
-		if (e != hipSuccess) rc = fail(JP_ERR_DEVICE, std::string("jp_bsdf: ") + hipGetErrorString(e));
-	} while (0);
-	hipFree(din); hipFree(dout); hipFree(dfl);
-	return rc;
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (c->d_bsdf_in) hipFree(c->d_bsdf_in); if (c->d_bsdf_out) hipFree(c->d_bsdf_out); if (c->d_bsdf_fl) hipFree(c->d_bsdf_fl);
+		c->d_bsdf_in = c->d_bsdf_out = nullptr; c->d_bsdf_fl = nullptr; c->bsdf_cap = 0;
+		const size_t cap = std::max<size_t>((size_t)n, 256);
+		if (hipMalloc((void**)&c->d_bsdf_in, cap * 11 * 4) != hipSuccess || hipMalloc((void**)&c->d_bsdf_out, cap * 11 * 4) != hipSuccess || hipMalloc((void**)&c->d_bsdf_fl, cap * 4) != hipSuccess)
+			return fail(JP_ERR_DEVICE, "jp_bsdf: out of device memory");
+		c->bsdf_cap = cap;
+	}
+	float *dn = c->d_bsdf_in, *dwo = dn + 3 * (size_t)n, *dwi = dn + 6 * (size_t)n, *du = dn + 9 * (size_t)n;
+	float *df = c->d_bsdf_out, *dpe = df + 3 * (size_t)n, *dsf = df + 4 * (size_t)n, *dswi = df + 7 * (size_t)n, *dsp = df + 10 * (size_t)n;
+	int* dfl = c->d_bsdf_fl;
+	HIP_TRY(hipMemcpyAsync(dn, normal, (size_t)n * 12, hipMemcpyHostToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(dwo, wo, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipMemcpyAsync(dwi, wi, (size_t)n * 12, hipMemcpyHostToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(du, u, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+	const int grid = std::min(c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK);
+	hipLaunchKernelGGL(k_bsdf, dim3(grid), dim3(JP_BLOCK), 0, c->stream, *d, n, (const float*)dn, (const float*)dwo, (const float*)dwi, (const float*)du, df, dpe, dsf, dswi, dsp, dfl);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(f_eval, df, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipMemcpyAsync(pdf_eval, dpe, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(s_f, dsf, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipMemcpyAsync(s_wi, dswi, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(s_pdf, dsp, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipMemcpyAsync(s_flags, dfl, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return JP_OK;
 }
 
 int jp_trace(JpContext* c, int32_t n, const float* origin, const float* dir, const float* tmin, const float* tmax, int32_t* hit, float* t, int32_t* prim, float* normal)

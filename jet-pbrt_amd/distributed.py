@@ -1,5 +1,7 @@
 """Multi-GPU plumbing: one process per GPU, 20-row bands of the film dealt round-robin to the ranks, one
-reduce(sum) of the per-rank films onto rank 0 (RCCL over xGMI on the GPU box; gloo in the CPU tests).
+collective that assembles the film on rank 0 (RCCL over xGMI on the GPU box; gloo in the CPU tests): `assemble_bands`
+-- every rank sends only ITS rows, packed (1/N of the film per rank; round 3) -- when the bands deal evenly, else one
+reduce(sum) of the per-rank films.
 
 The path shards by pixels with no data-path exchange: a rank's film is zero outside its
 bands, so the sum over ranks is the disjoint union and -- with the counter sampler -- bit-identical to the
@@ -36,5 +38,30 @@ def render_sharded(render_fn, width, height, spp, max_depth=5, seed=1234, band_r
         return render_fn(shard_params(width, height, spp, 0, 1, max_depth, seed, band_rows))
     rank, world = dist.get_rank(), dist.get_world_size()
     film = render_fn(shard_params(width, height, spp, rank, world, max_depth, seed, band_rows))
-    dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
-    return film if rank == 0 else None
+    return assemble_bands(film, height, band_rows, dist)
+
+
+def assemble_bands(film, height, band_rows, dist):
+    """The film of this rank (H, W, 3; zero outside its bands) -> the full film on rank 0 (None elsewhere), moving only the rank's own
+    rows: the bands b % world == rank are packed into one contiguous (rows/world, W, 3) tensor, one gather brings the packed shards
+    to rank 0, which writes them back to their rows.  1/N of the film per rank on the wire instead of the whole film per rank of a
+    reduce(sum) (FFilm::AddColor onto a zero film, film.h:64-68: disjoint bands, nothing to add).  Needs bands that deal evenly
+    (balanced_band_rows); otherwise the reduce of render_sharded serves."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    nb = height // band_rows
+    if height % band_rows != 0 or nb % world != 0:
+        dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+        return film if rank == 0 else None
+    W = film.shape[1]
+    view = film.view(nb // world, world, band_rows, W, 3)            # band b = (b // world, b % world)
+    mine = view[:, rank].contiguous()
+    parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, gather_list=parts, dst=0)
+    if rank != 0:
+        return None
+    out = torch.empty_like(film)
+    ov = out.view(nb // world, world, band_rows, W, 3)
+    for r in range(world):
+        ov[:, r] = parts[r]
+    return out

@@ -97,7 +97,7 @@ int jp_host_render(void* h, int W, int H, int spp, int maxdepth, unsigned seed, 
 	FCounterSampler sampler(spp, seed);
 	hs->integ->Render(hs->scene.get(), &sampler, &film, 16);
 	if (hs->integ->LastStatus() != JP_OK) return hs->integ->LastStatus();
-	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const FColor& c = film(x, y); float* o = film_out + 3 * ((size_t)y * W + x); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
+	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const FColor& c = static_cast<const FFilm&>(film)(x, y); float* o = film_out + 3 * ((size_t)y * W + x); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
 	if (counters) *counters = hs->integ->Counters();
 	return JP_OK;
 }
@@ -112,7 +112,7 @@ int jp_host_render_other(void* h, int kind, int W, int H, int spp, int maxdepth,
 	FCounterSampler sampler(spp, seed);
 	integ->Render(hs->scene.get(), &sampler, &film, 16);
 	if (integ->LastStatus() != JP_OK) return integ->LastStatus();
-	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const FColor& c = film(x, y); float* o = film_out + 3 * ((size_t)y * W + x); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
+	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const FColor& c = static_cast<const FFilm&>(film)(x, y); float* o = film_out + 3 * ((size_t)y * W + x); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
 	return JP_OK;
 }
 
@@ -121,6 +121,7 @@ int jp_host_render_other(void* h, int kind, int W, int H, int spp, int maxdepth,
 int jp_host_render_ldr(void* h, int W, int H, int spp, int maxdepth, unsigned seed, int device, int ldr_only, unsigned char* rgb8_out, float* film_out, const char* filename, int type)
 {
 	HostScene* hs = (HostScene*)h;
+	if (ldr_only && ((filename && filename[0] && type == 2) || film_out)) return JP_ERR_INVALID_ARGUMENT;   // an LDR-only film has no fp32 pixels for an .hdr file or a float buffer
 	if (!hs->integ || hs->integDepth != maxdepth) { hs->integ.reset(new FGpuPathIntegrator(maxdepth, device)); hs->integDepth = maxdepth; }
 	hs->integ->SetShard(0, 1);
 	FFilm film(W, H);
@@ -130,7 +131,7 @@ int jp_host_render_ldr(void* h, int W, int H, int spp, int maxdepth, unsigned se
 	if (hs->integ->LastStatus() != JP_OK) return hs->integ->LastStatus();
 	if (!film.HasLDR()) return JP_ERR_DEVICE;
 	if (rgb8_out) std::memcpy(rgb8_out, film.ldr8.data(), film.ldr8.size());
-	if (film_out) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const FColor& c = film(x, y); float* o = film_out + 3 * ((size_t)y * W + x); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
+	if (film_out) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const FColor& c = static_cast<const FFilm&>(film)(x, y); float* o = film_out + 3 * ((size_t)y * W + x); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
 	if (filename && filename[0]) return film.SaveAsImage(filename, type == 0 ? EImageType::PPM : (type == 2 ? EImageType::HDR : EImageType::BMP)) ? JP_OK : JP_ERR_INVALID_ARGUMENT;
 	return JP_OK;
 }
@@ -163,7 +164,7 @@ int jp_host_render_sampler(void* h, int sampler, int W, int H, int spp, int maxd
 	if (sampler == 2) s.reset(new FDebugSampler(spp)); else if (sampler == 1) s.reset(new FStratifiedSampler(spp)); else s.reset(new FRandomSampler(spp));
 	integ.Render(hs->scene.get(), s.get(), &film, 16);
 	if (integ.LastStatus() != JP_OK) return integ.LastStatus();
-	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const FColor& c = film(x, y); float* o = film_out + 3 * ((size_t)y * W + x); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
+	for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const FColor& c = static_cast<const FFilm&>(film)(x, y); float* o = film_out + 3 * ((size_t)y * W + x); o[0] = c.r; o[1] = c.g; o[2] = c.b; }
 	return JP_OK;
 }
 

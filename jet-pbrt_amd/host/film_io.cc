@@ -90,7 +90,7 @@ bool FFilm::SaveAsImage(const std::string& filename, EImageType imgType) const
 	{
 	case EImageType::PPM: return WritePPM(filename + ".ppm", width, height, Pixels8(width, height, pixels, ldr8));
 	case EImageType::BMP: return WriteBMP(filename + ".bmp", width, height, Pixels8(width, height, pixels, ldr8));
-	case EImageType::HDR: return WriteHDR(filename + ".hdr", width, height, pixels);
+	case EImageType::HDR: return floatValid ? WriteHDR(filename + ".hdr", width, height, pixels) : false;   // an LDR-only render left no fp32 pixels to write
 	}
 	return false;
 }

@@ -61,11 +61,19 @@ struct BsdfOut { float f[3], pdf, sf[3], swi[3], spdf; int32_t flags; bool ok; }
 BsdfOut DeviceBsdf(const JpBsdfDesc& d, const FVector3& n, const FVector3& wo, const FVector3& wi, const FVector2& u)
 {
 	static JpContext* bctx = nullptr; static std::mutex mu;
+	// the context lives on the device this process renders on (JETPBRT_DEVICE, else LOCAL_RANK, else 0 -- under HIP_VISIBLE_DEVICES
+	// that is the rank's own GPU) and is destroyed at exit
 	BsdfOut o; std::memset(&o, 0, sizeof(o));
 	HipApi& api = Api();
 	if (!api.lib) { fprintf(stderr, "FBSDF: HIP library not available (%s)\n", api.error.c_str()); return o; }
 	std::lock_guard<std::mutex> lock(mu);
-	if (!bctx && api.create_context(0, &bctx) != JP_OK) { fprintf(stderr, "FBSDF: %s\n", api.last_error()); bctx = nullptr; return o; }
+	if (!bctx)
+	{
+		int dev = 0;
+		if (const char* e = getenv("JETPBRT_DEVICE")) dev = atoi(e); else if (const char* r = getenv("LOCAL_RANK")) dev = atoi(r);
+		if (api.create_context(dev, &bctx) != JP_OK && (dev == 0 || api.create_context(0, &bctx) != JP_OK)) { fprintf(stderr, "FBSDF: %s\n", api.last_error()); bctx = nullptr; return o; }
+		atexit([]() { if (bctx) { Api().destroy_context(bctx); bctx = nullptr; } });
+	}
 	const float nn[3] = { n.x, n.y, n.z }, a[3] = { wo.x, wo.y, wo.z }, b[3] = { wi.x, wi.y, wi.z }, uu[2] = { u.x, u.y };
 	if (api.bsdf(bctx, &d, 1, nn, a, b, uu, o.f, &o.pdf, o.sf, o.swi, &o.spdf, &o.flags) != JP_OK) { fprintf(stderr, "FBSDF: %s\n", api.last_error()); return o; }
 	o.ok = true;
@@ -121,11 +129,11 @@ void FGpuPathIntegrator::Render(const FScene* scene, FSampler* sampler, FFilm* f
 	rp.band_rows = bandRows; rp.shard_index = shardIndex; rp.shard_count = shardCount; rp.integrator = kind;
 	const bool floatFilm = !(film->wantLDR && film->ldrOnly);
 	std::vector<float> rgb(floatFilm ? (size_t)rp.width * rp.height * 3 : 0);
+	std::vector<uint8_t> ldr;
 	if (film->wantLDR)
 	{   // FFilm::RequestDeviceLDR: gamma_encoding (film.h:24) runs on the GPU, the film comes back as 3 bytes per pixel
-		film->ldr8.assign((size_t)rp.width * rp.height * 3, 0);
-		lastStatus = api.render_rgb8(ctx, &rp, film->ldr8.data(), floatFilm ? rgb.data() : nullptr);
-		if (lastStatus != JP_OK) film->ldr8.clear();
+		ldr.assign((size_t)rp.width * rp.height * 3, 0);
+		lastStatus = api.render_rgb8(ctx, &rp, ldr.data(), floatFilm ? rgb.data() : nullptr);
 	}
 	else lastStatus = api.render(ctx, &rp, rgb.data());
 	if (lastStatus != JP_OK) { fprintf(stderr, "FGpuPathIntegrator::Render: %s\n", api.last_error()); return; }
@@ -135,6 +143,7 @@ void FGpuPathIntegrator::Render(const FScene* scene, FSampler* sampler, FFilm* f
 			const float* p = &rgb[3 * ((size_t)y * rp.width + x)];
 			film->AddColor(x, y, FColor(p[0], p[1], p[2]));               // integrator.cc:108 / film.h:64-68
 		}
+	if (film->wantLDR) { film->ldr8.swap(ldr); film->floatValid = floatFilm; }   // (after AddColor: any later change of a pixel drops the bytes again)
 	api.get_counters(ctx, &counters);
 	fprintf(stderr, "finish rendering ...\n");
 	fprintf(stderr, "FIntegrator::Render used %f seconds.\n", (float)(counters.render_ms / 1000.0));   // integrator.cc:77-79

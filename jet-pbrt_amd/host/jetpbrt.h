@@ -230,9 +230,12 @@ public:
 	FFilm(int w, int h) : width(w), height(h), pixels((size_t)w * h) {}
 	int Width() const { return width; } int Height() const { return height; }
 	FVector2 GetResolution() const { return FVector2((Float)width, (Float)height); }
-	FColor& operator()(int x, int y) { return pixels[(size_t)width * y + x]; }
+	// (writable access: the 8-bit bytes the device delivered describe the film as it was rendered, so any change drops them)
+	FColor& operator()(int x, int y) { InvalidateLDR(); return pixels[(size_t)width * y + x]; }
+	const FColor& operator()(int x, int y) const { return pixels[(size_t)width * y + x]; }
 	void AddColor(int x, int y, const FColor& c) { FColor& p = (*this)(x, y); p.r += c.r; p.g += c.g; p.b += c.b; }
-	void Clear() { for (auto& p : pixels) p = FColor(); }
+	void Clear() { InvalidateLDR(); for (auto& p : pixels) p = FColor(); }
+	void InvalidateLDR() { if (!ldr8.empty()) { ldr8.clear(); floatValid = true; } }
 	// the output step right after the hot path (main.cc:160): <filename>.ppm/.bmp/.hdr, gamma 1/2.2 for the 8-bit formats
 	bool SaveAsImage(const std::string& filename, EImageType imgType) const;
 	// Tone mapping on the GPU: ask the integrator for the film as 8-bit gamma-encoded RGB (gamma_encoding of film.h:24 applied on
@@ -242,6 +245,7 @@ public:
 	bool HasLDR() const { return ldr8.size() == (size_t)width * height * 3; }
 	int width, height; std::vector<FColor> pixels;
 	bool wantLDR = false, ldrOnly = false; std::vector<uint8_t> ldr8;   // R G B per pixel, top row first
+	bool floatValid = true;                                            // false after an LDR-only render: the fp32 pixels were not downloaded
 };
 
 // ---- reflection API (bsdf.h, bsdf.cc, microfacet.h, microfacet.cc) --------------------------------------------------------

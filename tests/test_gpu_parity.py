@@ -800,12 +800,18 @@ def test_config3_full_size_default_path_vs_reference_tree(H, gpu_ctx):
         assert rctx.build_info().traversal_mode == 5
         ref = rctx.render(H.jp.render_params(W, Hh, spp))
         rc = rctx.counters()
-        # the link to the CPU oracle, in this very run: one band of the reference-tree film at a reduced sample count
+        # the link to the CPU oracle, in this very run: twenty rows of the reference-tree film spread over the whole image (2-row bands
+        # j with j % 30 == 8: ten tasks, so ten oracle threads) at 192 spp -- sample indices far beyond the first few, rows through
+        # the meshes, the floor and the sky -- strictly equal (round 3; round 2 linked one band at 4 spp)
         b = 17
-        p = H.jp.render_params(W, Hh, 4, shard_index=b, shard_count=30)
+        p = H.jp.render_params(W, Hh, 192, band_rows=2, shard_index=8, shard_count=30)
         gband = rctx.render(p)
         H.libc_srand(1)
         oband, _ = H.oracle_render(rsp, p, len(os.sched_getaffinity(0)))
+        rows = np.zeros(Hh, bool)
+        for y0, y1 in H.jp.distributed.bands_of(Hh, 8, 30, 2):
+            rows[y0:y1] = True
+        assert rows.sum() == 20 and np.abs(gband[~rows]).max() == 0
         if rctx.build_info().libm_sincosf != 0:
             assert np.array_equal(gband.view(np.uint32), oband.view(np.uint32))
         else:

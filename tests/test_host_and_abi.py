@@ -292,3 +292,12 @@ def test_kernel_register_budgets(H, tmp_path):
     assert all(r["waves"] >= 3 for n, r in rows.items() if n.startswith("k_path"))
     spills = [n for n, r in rows.items() if r["scratch"] and not n.startswith(("k_other", "k_wide_level", "k_path"))]
     assert not spills, spills
+
+
+def test_gamma_threshold_table_is_exact_for_every_float(H):
+    """jp_render_rgb8's tone map counts host-derived thresholds <= x; the table is found by binary search, which assumes the host's
+    powf-based gamma_encoding (film.h:24) never steps down.  Sweep EVERY fp32 bit pattern of [0, 1] (1,065,353,217 values) through
+    both: zero differences, so the device bytes equal the host's for every input, not only for the sampled ones"""
+    lib = C.CDLL(H.jp.HIP_LIB_PATH)
+    lib.jp_gamma_sweep.restype = C.c_longlong
+    assert lib.jp_gamma_sweep(len(os.sched_getaffinity(0))) == 0

@@ -38,7 +38,7 @@ def _worker(rank, world, port, W, Hh, spp, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("W,Hh,spp", [(40, 70, 2)])
+@pytest.mark.parametrize("W,Hh,spp", [(40, 70, 2), (40, 80, 2)])      # 70 rows: uneven bands -> reduce(sum); 80 rows: 4 bands -> packed gather
 def test_two_rank_band_shard_equals_single_rank(H, tmp_path, W, Hh, spp):
     out = str(tmp_path / "film.npy")
     port = 29500 + (os.getpid() % 1000)
