@@ -2434,9 +2434,13 @@ PathKernel path_kernel(const JpContext* c)
 	switch (c->trav_mode)
 	{
 	case 2: return so ? k_path<2, 2, true, true, true> : k_path<2, 2, true, false, true>;
-	case 3: return so ? k_path<0, 3, false, true, true> : k_path<0, 3, false, false, true>;
+	case 3:
+		if (c->use_q4) return c->q4_shadow ? (so ? k_path<4, 4, false, true, true> : k_path<4, 4, false, false, true>) : (so ? k_path<4, 3, false, true, true> : k_path<4, 3, false, false, true>);
+		return so ? k_path<0, 3, false, true, true> : k_path<0, 3, false, false, true>;
 	case 5: return so ? k_path<5, 5, false, true, false> : k_path<5, 5, false, false, false>;
-	default: return so ? k_path<0, 0, false, true, true> : k_path<0, 0, false, false, true>;
+	default:
+		if (c->use_q4) return so ? k_path<4, 4, false, true, true> : k_path<4, 4, false, false, true>;
+		return so ? k_path<0, 0, false, true, true> : k_path<0, 0, false, false, true>;
 	}
 }
 
@@ -2480,7 +2484,7 @@ int render_fused(JpContext* c, const JpRenderParams* rp, float* film_dev, bool s
 		int S = 16;
 		if (const char* e = getenv("JETPBRT_JOB_SPP")) { int v = atoi(e); if (v >= 1 && v <= 128) S = v; }
 		const int n_tab = 2 * c->sv.n_lights + 4 * c->sv.n_mats + (c->sv.n_mats + 3) / 4, n_tab_all = n_tab + (flat ? 8 * c->sv.n_prims : 0);
-		const int deepE = c->stack_depth, deepS = c->trav_mode == 3 ? (int)(c->lds_bytes_shadow / (JP_BLOCK * sizeof(int))) : c->stack_depth;
+		const int deepE = c->stack_depth, deepS = (c->trav_mode == 3 && !c->q4_shadow) ? (int)(c->lds_bytes_shadow / (JP_BLOCK * sizeof(int))) : c->stack_depth;
 		const int ecap = flat ? 0 : std::min(deepE, c->stack_lds_words), scap = flat ? 0 : std::min(deepS, c->stack_lds_words);
 		PathLds L = path_lds_layout(modeE, n_tab_all, c->sv.n_prims, R, c->n_planes, ecap, scap, c->shade_sort);
 		while (L.total > 64 * 1024 && R > JP_BLOCK) { R -= JP_BLOCK; L = path_lds_layout(modeE, n_tab_all, c->sv.n_prims, R, c->n_planes, ecap, scap, c->shade_sort); }
@@ -2529,7 +2533,7 @@ int render_fused(JpContext* c, const JpRenderParams* rp, float* film_dev, bool s
 		HIP_TRY(hipMemsetAsync(c->d_jobs, 0, (size_t)nbatches * 4, c->stream));
 		{   // spill area of the walkers' stacks beyond the words kept in LDS
 			const int deep = std::max(deepE, deepS);
-			const size_t need = !flat && deep > c->stack_lds_words ? (size_t)(deep - c->stack_lds_words) * G * JP_BLOCK : 1;
+			const size_t need = !flat && deep >= c->stack_lds_words ? (size_t)(deep - c->stack_lds_words + 1) * G * JP_BLOCK : 1;   // (+1: Walker<4>'s dump slot)
 			if (c->spill_words < need) { HIP_TRY(hipStreamSynchronize(c->stream)); if (c->d_spill) hipFree(c->d_spill); c->d_spill = nullptr; c->spill_words = 0; HIP_TRY(hipMalloc((void**)&c->d_spill, need * sizeof(int))); c->spill_words = need; }
 		}
 		if (c->pix_acc_n < (size_t)npix) { HIP_TRY(hipStreamSynchronize(c->stream)); if (c->d_pix_acc) hipFree(c->d_pix_acc); c->d_pix_acc = nullptr; HIP_TRY(hipMalloc((void**)&c->d_pix_acc, (size_t)npix * 16)); c->pix_acc_n = (size_t)npix; }

@@ -75,7 +75,8 @@ __device__ unsigned long long g_path_t[16];
 #endif
 
 // kModeE / kModeS: traversal of closest-hit / shadow rays -- 2 flat leaf list (tiny scenes, primitives in LDS), 0 binary tree,
-// 3 8-wide quantised tree, 5 reference semantics; modes 0 / 3 / 5 run the resumable walkers with lane refill (jp_device.h).
+// 3 8-wide quantised tree, 4 4-wide quantised tree, 5 reference semantics; modes 0 / 3 / 4 / 5 run the resumable walkers with lane
+// refill (jp_device.h).
 template <int kModeE, int kModeS, bool kPrims, bool kSort, bool kVote>
 __global__ void __launch_bounds__(JP_BLOCK, JP_PATH_WAVES) k_path(SceneView sc, Queues q, RenderConst rc, PathConst pc, int* spill, DevCounters* cnt)
 {
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(JP_BLOCK, JP_PATH_WAVES) k_path(SceneView sc, 
 			else
 			{   // lane refill (k_extend_persist): a lane that finished its ray takes the next one of the region
 				__syncthreads();                                     // s_ctr[5] = 0 is visible
-				const WalkStack estack = { (int*)s_scr + tid, spill + blockIdx.x * JP_BLOCK + tid, pc.ecap, gridDim.x * JP_BLOCK };
+				const WalkStack estack = { (int*)s_scr + tid, spill + blockIdx.x * JP_BLOCK + tid, kModeE == 4 ? pc.ecap - 1 : pc.ecap, gridDim.x * JP_BLOCK };   // (Walker<4>: the last LDS word is its dump slot)
 				Walker<kModeE> w; w.done = true; w.hit = -1; w.tmax = JP_INF;
 				unsigned int ridx = 0xffffffffu, c_hit = 0;
 				bool pool = true;
@@ -505,7 +506,7 @@ __global__ void __launch_bounds__(JP_BLOCK, JP_PATH_WAVES) k_path(SceneView sc, 
 					for (unsigned int i = tid; i < (total + 31) / 32; i += JP_BLOCK) s_occ[i] = 0;
 					if (tid == 0) s_ctr[5] = 0;
 					__syncthreads();
-					const WalkStack sstack = { (int*)s_scr + tid, spill + blockIdx.x * JP_BLOCK + tid, pc.scap, gridDim.x * JP_BLOCK };
+					const WalkStack sstack = { (int*)s_scr + tid, spill + blockIdx.x * JP_BLOCK + tid, kModeS == 4 ? pc.scap - 1 : pc.scap, gridDim.x * JP_BLOCK };
 					Walker<kModeS> w; w.done = true; w.hit = -1;
 					unsigned int rid = 0xffffffffu;
 					bool pool = true;

@@ -1128,7 +1128,8 @@ def test_four_wide_quantised_tree_hit_records_and_film(H, monkeypatch):
     assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32))
     assert (prim == oprim).mean() > 0.9999
     assert np.array_equal(hit, hit2) and np.array_equal(t.view(np.uint32), t2.view(np.uint32)) and (prim == prim2).mean() > 0.9999
-    for env in ({"JETPBRT_Q4": "0"}, {"JETPBRT_Q4_SHADOW": "0"}, {"JETPBRT_STACK_LDS": "2"}, {"JETPBRT_PERSIST": "8", "JETPBRT_VOTE": "0"}):
+    for env in ({"JETPBRT_Q4": "0"}, {"JETPBRT_Q4_SHADOW": "0"}, {"JETPBRT_STACK_LDS": "2"}, {"JETPBRT_PERSIST": "8", "JETPBRT_VOTE": "0"},
+                {"JETPBRT_FUSED": "1"}, {"JETPBRT_FUSED": "1", "JETPBRT_Q4_SHADOW": "0"}, {"JETPBRT_FUSED": "1", "JETPBRT_STACK_LDS": "4"}):   # (k_path<4, 4> / <4, 3>)
         c = ctx_with(env)
         try:
             assert (c.build_info().q4_nodes == 0) == (env.get("JETPBRT_Q4") == "0")
