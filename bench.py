@@ -10,8 +10,9 @@ already resident in HBM, film download included.  The HEA
 configs[2] -- the reference's own Cornell scene (main.cc:27-33: metal tall box) at 512x512, 1024 spp -- timed over EXACTLY
 --steps frames after --warmup untimed ones.  At N = 1 the line also carries a `configs` object with one full sub-record per
 single-GPU configuration of BASELINE.json (configs[1] Lambertian-only Cornell, configs[2] full materials, configs[3] the
-bunny scene of main.cc:64-111 at 800x600, 2048 spp): each is timed over its own region of >= --min-seconds (default 10 s)
-and carries value, ms_per_step, roofline, cpu_baseline and l2_vs_cpu_ref.
+bunny scene of main.cc:64-111 at 800x600, 2048 spp): each is timed over its own region of >= --min-seconds (default 10 s);
+their figures are summarised in `config.sub` of the one stdout line, the full sub-records (roofline, cpu_baseline,
+l2_vs_cpu_ref) are written to stderr as one `configs_detail {...}` line.
 
 At N > 1 the row bands of the film (the reference's FRenderTask unit, integrator.cc:53: 20 rows; here the largest height
 <= 20 that deals evenly) are dealt round-robin to the ranks, each rank renders its bands into a device film that is zero
@@ -417,7 +418,9 @@ def main():
                 "l2": (None if not v.get("l2_vs_cpu_ref") else r4(v["l2_vs_cpu_ref"]["mean_per_pixel_l2"])),
                 "identical": (None if not v.get("l2_vs_cpu_ref") else (v["l2_vs_cpu_ref"].get("bit_identical") if "bit_identical" in v["l2_vs_cpu_ref"] else round(v["l2_vs_cpu_ref"].get("fraction_pixels_identical", 0), 4))),
                 "cpu_ref_Msamples_s": (None if not v.get("cpu_baseline") else v["cpu_baseline"]["value"])} for k, v in subs.items()}
-            out["configs"] = subs
+            # the full sub-records (roofline, cpu_baseline, l2_vs_cpu_ref of every config) go to stderr: the ONE line on stdout stays
+            # small enough for a log tail to keep whole, with every sub-record's figures in config.sub
+            sys.stderr.write("configs_detail " + json.dumps(subs, separators=(",", ":")) + "\n"); sys.stderr.flush()
         print(json.dumps(out, separators=(",", ":")), flush=True)
     if dist is not None:
         dist.barrier()

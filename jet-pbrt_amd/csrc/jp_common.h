@@ -42,6 +42,7 @@ struct RenderConst
 	int s0, sbatch;      // first sample index and sample count of this batch
 	int n_planes;        // shadow ray planes (lights that can emit)
 	int tiled;           // pixel enumeration: 16 x 4 tiles (1) or row-major (0)
+	int compact;         // k_raygen: a region takes consecutive (pixel block, sample) chunks (1) or an even sample of the image (0)
 	int slot_bits;       // a shadow entry's header word: slot in the low slot_bits bits, ray count above (27 + 5, or 24 + 8 for scenes with more than 31 emitting lights)
 	int sampler_debug;   // JP_SAMPLER_DEBUG: every draw is 0.5
 	int class_mask;      // material classes present in the scene (bit 0: none / null material, bit 1 + JP_MAT_*), k_shade<kSort>

@@ -97,8 +97,16 @@ __global__ void __launch_bounds__(JP_BLOCK) k_raygen(SceneView sc, Queues q, Ren
 	const unsigned int G = gridDim.x, b = blockIdx.x;
 	if (b == 0 && threadIdx.x == 0) { cnt->n_queue[0] = total; cnt->n_queue[1] = 0; cnt->n_shadow = 0; }
 	unsigned int filled = 0;
-	for (unsigned int c = b, j0 = 0; c < nchunks; c += G, j0 += JP_BLOCK)
+	// rc.compact (large scenes, round 3): region b takes CONSECUTIVE chunks of the list ordered by (256-pixel block, sample): a region is a
+	// few pixel blocks with all their samples, and the ~2000 workgroups in flight cover one part of the image, so the nodes and
+	// primitives their rays fetch are the same few MB (the L2 of an XCD holds 4 MB of a 27 MB scene).  Otherwise (scenes in LDS) the
+	// chunks b, b + G, ...: an even sample of the image per region, regions age alike.
+	const unsigned int K = (nchunks + G - 1) / G, npb = (unsigned int)rc.npix / JP_BLOCK;
+	for (unsigned int k = 0, j0 = 0; k < K; k++, j0 += JP_BLOCK)
 	{
+		unsigned int c;
+		if (rc.compact) { const unsigned int qi = b * K + k; if (qi >= nchunks) break; const unsigned int pb = qi / (unsigned int)rc.sbatch, sl = qi - pb * (unsigned int)rc.sbatch; c = sl * npb + pb; }
+		else { c = b + k * G; if (c >= nchunks) break; }
 		const unsigned int slot = c * JP_BLOCK + threadIdx.x;
 		if (slot < total)
 		{
@@ -1296,6 +1304,7 @@ struct JpContext
 	bool have_scene = false;
 	SceneView sv; int stack_depth = 1; bool scene_in_lds = false, shade_prims_in_lds = false; size_t lds_bytes = 0, lds_bytes_shadow = 0;
 	void *d_flat = nullptr, *d_wide = nullptr, *d_cut = nullptr, *d_q4 = nullptr; bool ray_sort = false; int trav_mode = 0;
+	size_t trav_lds_pad = 0;                                                           // experiment: extra dynamic LDS of the refill kernels = fewer of their workgroups per CU (room for another lane's k_shade)
 	bool use_q4 = false, q4_shadow = false;                                            // closest-hit (and, as an experiment, shadow) rays walk the 4-wide quantised tree (Walker<4>)
 	bool vote = false; int persist = 0;                                             // lane refill in the closest-hit traversal of large scenes (k_extend_persist): refill threshold, 0 = off
 	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr, *d_shade_tab = nullptr;
@@ -2099,6 +2108,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.cut = (const float4*)c->d_cut; v.n_cut = (int)(cut.size() / 2);
 	v.wide = (const uint4*)c->d_wide; v.n_wide = dev_wide ? dev_n_wide : (int)(wide.size() / 20);
 	v.q4 = (const uint4*)c->d_q4; v.n_q4 = (int)(q4.size() / 16);
+	c->trav_lds_pad = 0; if (const char* e = getenv("JETPBRT_TRAV_LDS_PAD")) { const long v = atol(e); if (v > 0 && v <= 48 * 1024) c->trav_lds_pad = (size_t)v & ~(size_t)15; }
 	c->use_q4 = use_q4; c->q4_shadow = use_q4;                       // shadow rays too (measured against the 8-wide tree: k_shadow 53.8 -> 52.7 ms per 512 spp, frame +4 %)
 	if (const char* e = getenv("JETPBRT_Q4_SHADOW")) c->q4_shadow = use_q4 && atoi(e) != 0;
 	c->stack_depth = std::max(2, height + 2);
@@ -2272,6 +2282,11 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 		// together or not at all, which unbalances the workgroups) -> tiles only when traversal goes through global memory
 		rc.slot_bits = slot_bits;
 		rc.tiled = (c->trav_mode == 0 && rp->width % 16 == 0 && local_rows % 4 == 0 && !getenv("JETPBRT_NO_TILES")) ? 1 : 0;
+		// compact regions (k_raygen): scenes walked through global memory -- one lane on the 280k-triangle scene: k_extend 64.1 -> 55.8 ms,
+		// k_shadow 47.1 -> 40.5 ms per 512 spp (the workgroups in flight share an image area, hence tree nodes: L2), three lanes +1.2 %;
+		// films bit-identical.  JETPBRT_COMPACT_REGIONS=0 / 1 forces it.
+		rc.compact = (c->trav_mode != 2 && c->trav_mode != 1 && npix % JP_BLOCK == 0) ? 1 : 0;
+		if (const char* e = getenv("JETPBRT_COMPACT_REGIONS")) rc.compact = (atoi(e) != 0 && npix % JP_BLOCK == 0) ? 1 : 0;
 		const int grid = (int)G;
 		const size_t lds = c->lds_bytes;
 		for (int s0 = 0; s0 < rp->spp; s0 += sbatch)
@@ -2303,7 +2318,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 					Stamper t(c, CLS_EXTEND);
 					if (c->persist && (c->trav_mode == 0 || c->trav_mode == 3 || c->trav_mode == 5))
 					{
-						const int ecap = std::min(c->stack_depth, c->stack_lds_words); const size_t elds = (size_t)ecap * JP_BLOCK * sizeof(int);
+						const int ecap = std::min(c->stack_depth, c->stack_lds_words); const size_t elds = (size_t)ecap * JP_BLOCK * sizeof(int) + c->trav_lds_pad;
 						#define JP_LAUNCH_EP(M, R) do { if (c->vote) hipLaunchKernelGGL((k_extend_persist<M, R, true>), dim3(grid), dim3(JP_BLOCK), elds, c->stream, c->sv, c->q, cur, ecap, c->d_spill, c->d_cnt); else hipLaunchKernelGGL((k_extend_persist<M, R, false>), dim3(grid), dim3(JP_BLOCK), elds, c->stream, c->sv, c->q, cur, ecap, c->d_spill, c->d_cnt); } while (0)
 						if (c->trav_mode == 5) { if (c->persist >= 32) JP_LAUNCH_EP(5, 32); else if (c->persist >= 16) JP_LAUNCH_EP(5, 16); else JP_LAUNCH_EP(5, 8); }
 						else if (c->use_q4) { if (c->persist >= 32) JP_LAUNCH_EP(4, 32); else if (c->persist >= 16) JP_LAUNCH_EP(4, 16); else JP_LAUNCH_EP(4, 8); }
@@ -2335,7 +2350,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 					Stamper t(c, CLS_SHADOW);
 					const size_t slds = c->q4_shadow ? (size_t)c->stack_depth * JP_BLOCK * sizeof(int) : (c->trav_mode == 3 ? c->lds_bytes_shadow : lds);
 					const int scap = std::min((int)(slds / (JP_BLOCK * sizeof(int))), c->stack_lds_words);     // stack words per thread kept in LDS
-					const size_t plds = (size_t)scap * JP_BLOCK * sizeof(int) + (((size_t)c->q.R * c->n_planes + 31) / 32) * 4;
+					const size_t plds = (size_t)scap * JP_BLOCK * sizeof(int) + (((size_t)c->q.R * c->n_planes + 31) / 32) * 4 + c->trav_lds_pad;
 					if (c->persist && (c->trav_mode == 0 || c->trav_mode == 3 || c->trav_mode == 5) && plds <= 64 * 1024)
 					{
 						#define JP_LAUNCH_SP(M, R) do { if (c->vote) hipLaunchKernelGGL((k_shadow_persist<M, R, true>), dim3(grid), dim3(JP_BLOCK), plds, c->stream, c->sv, c->q, rc, scap, c->d_spill, c->d_cnt); else hipLaunchKernelGGL((k_shadow_persist<M, R, false>), dim3(grid), dim3(JP_BLOCK), plds, c->stream, c->sv, c->q, rc, scap, c->d_spill, c->d_cnt); } while (0)
@@ -2402,7 +2417,7 @@ void sync_lane_scene(JpContext* c, JpContext* l)
 	l->have_scene = c->have_scene; l->sv = c->sv; l->stack_depth = c->stack_depth; l->scene_in_lds = c->scene_in_lds; l->shade_prims_in_lds = c->shade_prims_in_lds;
 	l->lds_bytes = c->lds_bytes; l->lds_bytes_shadow = c->lds_bytes_shadow; l->trav_mode = c->trav_mode; l->n_planes = c->n_planes;
 	l->stack_lds_words = c->stack_lds_words;
-	l->use_q4 = c->use_q4; l->q4_shadow = c->q4_shadow;
+	l->use_q4 = c->use_q4; l->q4_shadow = c->q4_shadow; l->trav_lds_pad = c->trav_lds_pad;
 	l->ray_sort = c->ray_sort; l->persist = c->persist; l->vote = c->vote; l->shade_sort = c->shade_sort; l->class_mask = c->class_mask;
 	l->has_null_material = c->has_null_material; l->tables_in_lds = c->tables_in_lds; l->stage_nee = c->stage_nee; l->shade_lds_bytes = c->shade_lds_bytes;
 	l->profiling = c->profiling;
