@@ -1304,6 +1304,9 @@ struct JpContext
 	bool have_scene = false;
 	SceneView sv; int stack_depth = 1; bool scene_in_lds = false, shade_prims_in_lds = false; size_t lds_bytes = 0, lds_bytes_shadow = 0;
 	void *d_flat = nullptr, *d_wide = nullptr, *d_cut = nullptr, *d_q4 = nullptr; bool ray_sort = false; int trav_mode = 0;
+	// k_shadow of bounce b and k_extend of bounce b + 1 both depend on k_shade of bounce b only: with `dual` the shadow launches go to a second
+	// stream of the lane (own spill area) and run beside the next extend launch; the next k_shade waits for both
+	bool dual = false; hipStream_t stream2 = nullptr; hipEvent_t ev_shade = nullptr, ev_shadow = nullptr; int* d_spill2 = nullptr; size_t spill2_words = 0;
 	size_t trav_lds_pad = 0;                                                           // experiment: extra dynamic LDS of the refill kernels = fewer of their workgroups per CU (room for another lane's k_shade)
 	bool use_q4 = false, q4_shadow = false;                                            // closest-hit (and, as an experiment, shadow) rays walk the 4-wide quantised tree (Walker<4>)
 	bool vote = false; int persist = 0;                                             // lane refill in the closest-hit traversal of large scenes (k_extend_persist): refill threshold, 0 = off
@@ -1539,6 +1542,9 @@ int jp_destroy_context(JpContext* c)
 	free_fused(c);
 	if (c->d_pix_acc) hipFree(c->d_pix_acc);
 	if (c->d_spill) hipFree(c->d_spill);
+	if (c->d_spill2) hipFree(c->d_spill2);
+	if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+	if (c->ev_shade) hipEventDestroy(c->ev_shade); if (c->ev_shadow) hipEventDestroy(c->ev_shadow);
 	if (c->d_film) hipFree(c->d_film);
 	if (c->h_film) hipHostFree(c->h_film);
 	if (c->d_bsdf_in) hipFree(c->d_bsdf_in); if (c->d_bsdf_out) hipFree(c->d_bsdf_out); if (c->d_bsdf_fl) hipFree(c->d_bsdf_fl);
@@ -2108,6 +2114,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.cut = (const float4*)c->d_cut; v.n_cut = (int)(cut.size() / 2);
 	v.wide = (const uint4*)c->d_wide; v.n_wide = dev_wide ? dev_n_wide : (int)(wide.size() / 20);
 	v.q4 = (const uint4*)c->d_q4; v.n_q4 = (int)(q4.size() / 16);
+	c->dual = false; if (const char* e = getenv("JETPBRT_DUAL")) c->dual = atoi(e) != 0;
 	c->trav_lds_pad = 0; if (const char* e = getenv("JETPBRT_TRAV_LDS_PAD")) { const long v = atol(e); if (v > 0 && v <= 48 * 1024) c->trav_lds_pad = (size_t)v & ~(size_t)15; }
 	c->use_q4 = use_q4; c->q4_shadow = use_q4;                       // shadow rays too (measured against the 8-wide tree: k_shadow 53.8 -> 52.7 ms per 512 spp, frame +4 %)
 	if (const char* e = getenv("JETPBRT_Q4_SHADOW")) c->q4_shadow = use_q4 && atoi(e) != 0;
@@ -2189,15 +2196,15 @@ int ensure_queues(JpContext* c, unsigned int cap, int planes, unsigned int nbloc
 
 struct Stamper
 {
-	JpContext* c; int cls; size_t a;
-	Stamper(JpContext* c, int cls) : c(c), cls(cls), a(0)
+	JpContext* c; int cls; size_t a; hipStream_t st;
+	Stamper(JpContext* c, int cls, hipStream_t st_ = nullptr) : c(c), cls(cls), a(0), st(st_ ? st_ : c->stream)
 	{
 		if (!c->profiling) return;
 		if (c->evused + 2 > c->evpool.size()) { size_t old = c->evpool.size(); c->evpool.resize(old + 64); for (size_t i = old; i < c->evpool.size(); i++) hipEventCreate(&c->evpool[i]); }
 		a = c->evused; c->evused += 2;
-		hipEventRecord(c->evpool[a], c->stream);
+		hipEventRecord(c->evpool[a], st);
 	}
-	~Stamper() { if (!c->profiling) return; hipEventRecord(c->evpool[a + 1], c->stream); JpContext::Stamp s = { cls, a, a + 1 }; c->stamps.push_back(s); }
+	~Stamper() { if (!c->profiling) return; hipEventRecord(c->evpool[a + 1], st); JpContext::Stamp s = { cls, a, a + 1 }; c->stamps.push_back(s); }
 };
 
 int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sync, int lane_index = 0, int lane_count = 1, int lane_group = 4)
@@ -2272,6 +2279,11 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 			const int deep = std::max(c->stack_depth, c->trav_mode == 3 ? (int)(c->lds_bytes_shadow / (JP_BLOCK * sizeof(int))) : 0);
 			const size_t need = c->persist && deep >= c->stack_lds_words ? (size_t)(deep - c->stack_lds_words + 1) * G * JP_BLOCK : 1;   // (+1: Walker<4> keeps one LDS word as a dump slot)
 			if (c->spill_words < need) { if (c->d_spill) hipFree(c->d_spill); c->d_spill = nullptr; HIP_TRY(hipMalloc((void**)&c->d_spill, need * sizeof(int))); c->spill_words = need; }
+			if (c->dual && c->persist)
+			{
+				if (c->spill2_words < need) { if (c->d_spill2) hipFree(c->d_spill2); c->d_spill2 = nullptr; HIP_TRY(hipMalloc((void**)&c->d_spill2, need * sizeof(int))); c->spill2_words = need; }
+				if (!c->stream2) { HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->ev_shade, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->ev_shadow, hipEventDisableTiming)); }
+			}
 		}
 		if (c->pix_acc_n < (size_t)npix) { if (c->d_pix_acc) hipFree(c->d_pix_acc); c->d_pix_acc = nullptr; HIP_TRY(hipMalloc((void**)&c->d_pix_acc, (size_t)npix * 16)); c->pix_acc_n = (size_t)npix; }
 
@@ -2303,7 +2315,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 				else if (c->trav_mode == 1) hipLaunchKernelGGL(k_other<1>, dim3(ogrid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, rp->integrator, c->stack_depth, c->d_cnt);
 				else hipLaunchKernelGGL(k_other<0>, dim3(ogrid), dim3(JP_BLOCK), stack_lds, c->stream, c->sv, c->q, rc, rp->integrator, c->stack_depth, c->d_cnt);
 			}
-			int cur = 0;
+			int cur = 0; bool shadow_pending = false;
 			int iters = rp->integrator != JP_INTEGRATOR_PATH ? 0 : rp->max_depth + 1;
 			for (int it = 0;; it++)
 			{
@@ -2335,6 +2347,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 					else if (c->trav_mode == 1) hipLaunchKernelGGL(k_extend<1>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
 					else hipLaunchKernelGGL(k_extend<0>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, cur, c->stack_depth, c->d_cnt);
 				}
+				if (shadow_pending) { HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shadow, 0)); shadow_pending = false; }   // (k_shade rewrites the shadow queues and adds to the paths' radiance)
 				{
 					Stamper t(c, CLS_SHADE);
 					const bool st = c->stage_nee;
@@ -2347,13 +2360,16 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 				}
 				if (it < rp->max_depth || c->has_null_material)                 // at bounce == maxDepth Li() breaks before the NEE (integrator.cc:340-343)
 				{
-					Stamper t(c, CLS_SHADOW);
+					const bool two = c->dual && c->persist && c->stream2 && !c->has_null_material;
+					hipStream_t sstream = two ? c->stream2 : c->stream; int* sspill = two ? c->d_spill2 : c->d_spill;
+					if (two) { HIP_TRY(hipEventRecord(c->ev_shade, c->stream)); HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_shade, 0)); }
+					Stamper t(c, CLS_SHADOW, sstream);
 					const size_t slds = c->q4_shadow ? (size_t)c->stack_depth * JP_BLOCK * sizeof(int) : (c->trav_mode == 3 ? c->lds_bytes_shadow : lds);
 					const int scap = std::min((int)(slds / (JP_BLOCK * sizeof(int))), c->stack_lds_words);     // stack words per thread kept in LDS
 					const size_t plds = (size_t)scap * JP_BLOCK * sizeof(int) + (((size_t)c->q.R * c->n_planes + 31) / 32) * 4 + c->trav_lds_pad;
 					if (c->persist && (c->trav_mode == 0 || c->trav_mode == 3 || c->trav_mode == 5) && plds <= 64 * 1024)
 					{
-						#define JP_LAUNCH_SP(M, R) do { if (c->vote) hipLaunchKernelGGL((k_shadow_persist<M, R, true>), dim3(grid), dim3(JP_BLOCK), plds, c->stream, c->sv, c->q, rc, scap, c->d_spill, c->d_cnt); else hipLaunchKernelGGL((k_shadow_persist<M, R, false>), dim3(grid), dim3(JP_BLOCK), plds, c->stream, c->sv, c->q, rc, scap, c->d_spill, c->d_cnt); } while (0)
+						#define JP_LAUNCH_SP(M, R) do { if (c->vote) hipLaunchKernelGGL((k_shadow_persist<M, R, true>), dim3(grid), dim3(JP_BLOCK), plds, sstream, c->sv, c->q, rc, scap, sspill, c->d_cnt); else hipLaunchKernelGGL((k_shadow_persist<M, R, false>), dim3(grid), dim3(JP_BLOCK), plds, sstream, c->sv, c->q, rc, scap, sspill, c->d_cnt); } while (0)
 						if (c->trav_mode == 5) { if (c->persist >= 32) JP_LAUNCH_SP(5, 32); else if (c->persist >= 16) JP_LAUNCH_SP(5, 16); else JP_LAUNCH_SP(5, 8); }
 						else if (c->q4_shadow) { if (c->persist >= 32) JP_LAUNCH_SP(4, 32); else if (c->persist >= 16) JP_LAUNCH_SP(4, 16); else JP_LAUNCH_SP(4, 8); }
 						else if (c->trav_mode == 3) { if (c->persist >= 32) JP_LAUNCH_SP(3, 32); else if (c->persist >= 16) JP_LAUNCH_SP(3, 16); else JP_LAUNCH_SP(3, 8); }
@@ -2371,9 +2387,11 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 					else if (c->trav_mode == 2) hipLaunchKernelGGL(k_shadow<2>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 					else if (c->trav_mode == 1) hipLaunchKernelGGL(k_shadow<1>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 					else hipLaunchKernelGGL(k_shadow<0>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
+					if (two) { HIP_TRY(hipEventRecord(c->ev_shadow, c->stream2)); shadow_pending = true; }
 				}
 				cur ^= 1;
 			}
+			if (shadow_pending) { HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shadow, 0)); shadow_pending = false; }
 			{ Stamper t(c, CLS_OTHER); hipLaunchKernelGGL(k_resolve, dim3((unsigned int)std::min<long long>(c->n_cus * 8, (npix + JP_BLOCK - 1) / JP_BLOCK)), dim3(JP_BLOCK), 0, c->stream, c->q, rc, c->d_pix_acc, film_dev, s0 == 0 ? 1 : 0, s0 + rc.sbatch >= rp->spp ? 1 : 0); }
 			samples += (unsigned long long)rc.sbatch * (unsigned long long)npix;
 		}
@@ -2417,7 +2435,7 @@ void sync_lane_scene(JpContext* c, JpContext* l)
 	l->have_scene = c->have_scene; l->sv = c->sv; l->stack_depth = c->stack_depth; l->scene_in_lds = c->scene_in_lds; l->shade_prims_in_lds = c->shade_prims_in_lds;
 	l->lds_bytes = c->lds_bytes; l->lds_bytes_shadow = c->lds_bytes_shadow; l->trav_mode = c->trav_mode; l->n_planes = c->n_planes;
 	l->stack_lds_words = c->stack_lds_words;
-	l->use_q4 = c->use_q4; l->q4_shadow = c->q4_shadow; l->trav_lds_pad = c->trav_lds_pad;
+	l->use_q4 = c->use_q4; l->q4_shadow = c->q4_shadow; l->trav_lds_pad = c->trav_lds_pad; l->dual = c->dual;
 	l->ray_sort = c->ray_sort; l->persist = c->persist; l->vote = c->vote; l->shade_sort = c->shade_sort; l->class_mask = c->class_mask;
 	l->has_null_material = c->has_null_material; l->tables_in_lds = c->tables_in_lds; l->stage_nee = c->stage_nee; l->shade_lds_bytes = c->shade_lds_bytes;
 	l->profiling = c->profiling;

@@ -1130,6 +1130,7 @@ def test_four_wide_quantised_tree_hit_records_and_film(H, monkeypatch):
     assert np.array_equal(hit, hit2) and np.array_equal(t.view(np.uint32), t2.view(np.uint32)) and (prim == prim2).mean() > 0.9999
     for env in ({"JETPBRT_Q4": "0"}, {"JETPBRT_Q4_SHADOW": "0"}, {"JETPBRT_STACK_LDS": "2"}, {"JETPBRT_PERSIST": "8", "JETPBRT_VOTE": "0"},
                 {"JETPBRT_COMPACT_REGIONS": "0"}, {"JETPBRT_COMPACT_REGIONS": "1", "JETPBRT_LANES": "3"}, {"JETPBRT_COMPACT_REGIONS": "1", "JETPBRT_MAX_SLOTS": str(5 * 160 * 120)},   # region <- chunk mapping of k_raygen
+                {"JETPBRT_DUAL": "1"}, {"JETPBRT_DUAL": "1", "JETPBRT_LANES": "2", "JETPBRT_Q4_SHADOW": "0"},                # k_shadow on a second stream beside the next k_extend
                 {"JETPBRT_FUSED": "1"}, {"JETPBRT_FUSED": "1", "JETPBRT_Q4_SHADOW": "0"}, {"JETPBRT_FUSED": "1", "JETPBRT_STACK_LDS": "4"}):   # (k_path<4, 4> / <4, 3>)
         c = ctx_with(env)
         try:
