@@ -31,6 +31,7 @@
 #include <mutex>
 #include <thread>
 #include "jp_lbvh.h"
+#include "jp_ploc.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Wavefront-level sort: block-wide STABLE partition of a tile of kRPT x 256 queue entries by a small class key, with wave
@@ -1935,7 +1936,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 
 	// ---- no hierarchy handed over: records go up in creation order and the tree is built on the device (jp_lbvh.h) ----
 	size_t n4nodes = nodes.size(), n4prims = prims.size(), nmeta = meta.size();
-	bool dev_wide = false; int dev_n_wide = 0;
+	bool dev_wide = false; int dev_n_wide = 0; bool dev_q4 = false; int dev_n_q4 = 0;
 	c->build_on_device = device_build; c->build_ms = 0.f;
 	if (device_build)
 	{
@@ -1947,7 +1948,12 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		LbvhResult lr; std::vector<int> sorted;
 		int maxLeaf = 3;                                            // measured on the 280k-triangle scene: 540 / 578 / 579 / 560 / 534 / 497 Msamples/s for 1 / 2 / 3 / 4 / 6 / 8
 		if (const char* ev = getenv("JETPBRT_BVH_MAXLEAF")) { int v = atoi(ev); if (v >= 1 && v <= 16) maxLeaf = v; }
-		if (e == hipSuccess) e = lbvh_build(c->stream, (const float4*)d_p0, (const int4*)d_m0, s->n_primitives, maxLeaf, lr, sorted);
+		// [round 3] PLOC clustering (jp_ploc.h) instead of the Karras topology; JETPBRT_DEVICE_TREE=lbvh restores the latter, which also serves
+		// as the fallback should the clustering not finish within its round limit
+		bool ploc = true;
+		if (const char* ev = getenv("JETPBRT_DEVICE_TREE")) ploc = std::string(ev) != "lbvh";
+		if (e == hipSuccess && ploc) { e = ploc_build(c->stream, (const float4*)d_p0, (const int4*)d_m0, s->n_primitives, maxLeaf, lr, sorted); if (e == hipErrorNotReady) { e = hipSuccess; ploc = false; } }
+		if (e == hipSuccess && !ploc) e = lbvh_build(c->stream, (const float4*)d_p0, (const int4*)d_m0, s->n_primitives, maxLeaf, lr, sorted);
 		if (d_p0) hipFree(d_p0); if (d_m0) hipFree(d_m0);
 		if (e != hipSuccess) return fail(JP_ERR_DEVICE, std::string("jp_upload_scene: device BVH build failed: ") + hipGetErrorString(e));
 		if (lr.height + 2 > 60)
@@ -1968,6 +1974,16 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 			e = lbvh_build_wide(c->stream, (const float4*)c->d_nodes, s->n_primitives, wr);
 			if (e != hipSuccess) return fail(JP_ERR_DEVICE, std::string("jp_upload_scene: device wide-tree build failed: ") + hipGetErrorString(e));
 			if (wr.d_wide) { c->d_wide = wr.d_wide; dev_wide = true; dev_n_wide = wr.n_wide; wide_height = wr.height; use_wide = true; c->build_ms += wr.build_ms; }
+		}
+		// [round 3] ... and the 4-wide tree of Walker<4> for the closest-hit (and shadow) rays, as the host path has it
+		bool want_q4 = s->n_primitives > 1024;
+		if (const char* ev = getenv("JETPBRT_Q4")) want_q4 = want_q4 && atoi(ev) != 0;
+		if (want_q4)
+		{
+			WideResult qr;
+			e = lbvh_build_q4(c->stream, (const float4*)c->d_nodes, s->n_primitives, qr);
+			if (e != hipSuccess) return fail(JP_ERR_DEVICE, std::string("jp_upload_scene: device 4-wide tree build failed: ") + hipGetErrorString(e));
+			if (qr.d_wide) { c->d_q4 = qr.d_wide; dev_q4 = true; dev_n_q4 = qr.n_wide; c->build_ms += qr.build_ms; use_q4 = true; q4_height = qr.height; }
 		}
 	}
 	c->bvh_height = height; c->bvh_nodes = ref_sem ? s->n_bvh_nodes : (int)(n4nodes / 4);
@@ -2099,7 +2115,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		HIP_TRY(up(&c->d_shade_tab, tabv.data(), tabv.size() * sizeof(float4)));
 	}
 	if (use_wide && !dev_wide) HIP_TRY(up(&c->d_wide, wide.data(), wide.size() * sizeof(uint32_t)));
-	if (use_q4) HIP_TRY(up(&c->d_q4, q4.data(), q4.size() * sizeof(uint32_t)));
+	if (use_q4 && !dev_q4) HIP_TRY(up(&c->d_q4, q4.data(), q4.size() * sizeof(uint32_t)));
 	if (!flat.empty()) HIP_TRY(up(&c->d_flat, flat.data(), flat.size() * sizeof(float4)));
 	if (!cut.empty()) HIP_TRY(up(&c->d_cut, cut.data(), cut.size() * sizeof(float4)));
 
@@ -2113,7 +2129,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.flat = (const float4*)c->d_flat; v.n_flat = (int)(flat.size() / 2);
 	v.cut = (const float4*)c->d_cut; v.n_cut = (int)(cut.size() / 2);
 	v.wide = (const uint4*)c->d_wide; v.n_wide = dev_wide ? dev_n_wide : (int)(wide.size() / 20);
-	v.q4 = (const uint4*)c->d_q4; v.n_q4 = (int)(q4.size() / 16);
+	v.q4 = (const uint4*)c->d_q4; v.n_q4 = dev_q4 ? dev_n_q4 : (int)(q4.size() / 16);
 	c->dual = false; if (const char* e = getenv("JETPBRT_DUAL")) c->dual = atoi(e) != 0;
 	c->trav_lds_pad = 0; if (const char* e = getenv("JETPBRT_TRAV_LDS_PAD")) { const long v = atol(e); if (v > 0 && v <= 48 * 1024) c->trav_lds_pad = (size_t)v & ~(size_t)15; }
 	c->use_q4 = use_q4; c->q4_shadow = use_q4;                       // shadow rays too (measured against the 8-wide tree: k_shadow 53.8 -> 52.7 ms per 512 spp, frame +4 %)

@@ -563,4 +563,114 @@ static hipError_t lbvh_build_wide(hipStream_t stream, const float4* nodes, int n
 	r.d_wide = wide; r.n_wide = (int)h_ctr[0]; r.height = levels;
 	return hipSuccess;
 }
+// ---- [round 3] 4-wide quantised tree (Walker<4>, jp_device.h) collapsed on the device from the binary tree above --------------------
+// The same node format and the same collapse as the host builder of jp_upload_scene: from binary node b its two children, then the
+// interior child with the largest box is opened while fewer than four slots are taken; every child box gets 1e-6 of the node's extent
+// before it is quantised outward.  One thread builds one node, the tree grows level by level, a level's threads allocate the indices of
+// their interior children with one atomicAdd.  Leaves keep the binary tree's references (first << 4 | count - 1).
+__global__ void __launch_bounds__(64) k_q4_level(const float4* __restrict__ nodes, const WideItem* __restrict__ items, int n_items, uint32_t* __restrict__ q4,
+                                                 unsigned int* q4_count, WideItem* __restrict__ next, unsigned int* next_count, unsigned int max_nodes, int* fail)
+{
+	const int it = blockIdx.x * 64 + threadIdx.x;
+	if (it >= n_items) return;
+	const WideItem item = items[it];
+	int ref[4]; float box[4][6]; int nch = 0;
+	auto add_children_of = [&](int b, int at0, int at1) {
+		const float4 n0 = nodes[4 * b], n1 = nodes[4 * b + 1], n2 = nodes[4 * b + 2], n3 = nodes[4 * b + 3];
+		ref[at0] = __float_as_int(n3.x); box[at0][0] = n0.x; box[at0][1] = n0.y; box[at0][2] = n0.z; box[at0][3] = n0.w; box[at0][4] = n1.x; box[at0][5] = n1.y;
+		ref[at1] = __float_as_int(n3.y); box[at1][0] = n1.z; box[at1][1] = n1.w; box[at1][2] = n2.x; box[at1][3] = n2.y; box[at1][4] = n2.z; box[at1][5] = n2.w;
+	};
+	add_children_of(item.bnode, 0, 1); nch = 2;
+	while (nch < 4)
+	{
+		int best = -1; float bestA = -1.f;
+		for (int k = 0; k < nch; k++) if (ref[k] >= 0) { const float A = wide_area(box[k]); if (A > bestA) { bestA = A; best = k; } }
+		if (best < 0) break;
+		add_children_of(ref[best], best, nch); nch++;
+	}
+	float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+	for (int k = 0; k < nch; k++) for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], box[k][a]); hi[a] = fmaxf(hi[a], box[k][3 + a]); }
+	for (int k = 0; k < nch; k++) for (int a = 0; a < 3; a++) { const float ex = 1e-6f * (hi[a] - lo[a]); box[k][a] -= ex; box[k][3 + a] += ex; }
+	for (int a = 0; a < 3; a++) { const float ex = 1e-6f * (hi[a] - lo[a]); lo[a] -= ex; hi[a] += ex; }
+	int eb[3]; float sc[3];
+	for (int a = 0; a < 3; a++)
+	{
+		int e = (int)ceilf(log2f(fmaxf((hi[a] - lo[a]) / 255.f, 1e-30f)));
+		e = max(-120, min(120, e));
+		while (e < 120 && fmaf(255.f, ldexpf(1.0f, e), lo[a]) < hi[a]) e++;      // log2f is approximate: 255 steps must span the extent
+		eb[a] = e + 127; sc[a] = ldexpf(1.0f, e);
+	}
+	unsigned int ninner = 0; for (int k = 0; k < nch; k++) if (ref[k] >= 0) ninner++;
+	unsigned int child_base = 0, nbase = 0;
+	if (ninner)
+	{
+		child_base = atomicAdd(q4_count, ninner); if (child_base + ninner > max_nodes) { *fail = 1; return; }
+		nbase = atomicAdd(next_count, ninner);
+	}
+	unsigned char ql[3][4], qh[3][4]; uint32_t refs[4] = { 0, 0, 0, 0 }, valid = 0, rank = 0;
+	for (int k = 0; k < 4; k++) for (int a = 0; a < 3; a++) { ql[a][k] = 255; qh[a][k] = 0; }
+	for (int k = 0; k < nch; k++)
+	{
+		valid |= 1u << k;
+		if (ref[k] >= 0) { WideItem ni; ni.bnode = ref[k]; ni.widx = child_base + rank; next[nbase + rank] = ni; refs[k] = ni.widx; rank++; }
+		else refs[k] = (uint32_t)ref[k];
+		for (int a = 0; a < 3; a++)
+		{
+			int q0 = (int)floorf((box[k][a] - lo[a]) / sc[a]), q1 = (int)ceilf((box[k][3 + a] - lo[a]) / sc[a]);
+			q0 = max(0, min(255, q0)); q1 = max(0, min(255, q1));
+			while (q0 > 0 && fmaf((float)q0, sc[a], lo[a]) > box[k][a]) q0--;
+			while (q1 < 255 && fmaf((float)q1, sc[a], lo[a]) < box[k][3 + a]) q1++;
+			if (fmaf((float)q1, sc[a], lo[a]) < box[k][3 + a] || fmaf((float)q0, sc[a], lo[a]) > box[k][a]) *fail = 1;
+			ql[a][k] = (unsigned char)q0; qh[a][k] = (unsigned char)q1;
+		}
+	}
+	auto pack4 = [](const unsigned char* v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); };
+	uint32_t* w = &q4[(size_t)item.widx * 16];
+	w[0] = __float_as_uint(lo[0]); w[1] = __float_as_uint(lo[1]); w[2] = __float_as_uint(lo[2]);
+	w[3] = (uint32_t)eb[0] | ((uint32_t)eb[1] << 8) | ((uint32_t)eb[2] << 16) | (valid << 24);
+	w[4] = refs[0]; w[5] = refs[1]; w[6] = refs[2]; w[7] = refs[3];
+	w[8] = pack4(ql[0]); w[9] = pack4(ql[1]); w[10] = pack4(ql[2]); w[11] = pack4(qh[0]);
+	w[12] = pack4(qh[1]); w[13] = pack4(qh[2]); w[14] = 0; w[15] = 0;
+}
+
+// nodes: the device binary tree (root = node 0, always interior).  On failure r.d_wide stays null and the caller keeps the binary tree.
+static hipError_t lbvh_build_q4(hipStream_t stream, const float4* nodes, int n_prims, WideResult& r)
+{
+	r = WideResult();
+	if (n_prims < 2) return hipSuccess;
+	hipError_t e;
+	const unsigned int max_nodes = (unsigned int)std::max(16, n_prims);
+	uint32_t* q4 = nullptr; WideItem *fa = nullptr, *fb = nullptr; unsigned int* ctr = nullptr; int* fail = nullptr;
+	auto bail = [&](hipError_t err) { if (q4) hipFree(q4); if (fa) hipFree(fa); if (fb) hipFree(fb); if (ctr) hipFree(ctr); if (fail) hipFree(fail); return err; };
+	if ((e = hipMalloc((void**)&q4, (size_t)max_nodes * 64)) != hipSuccess || (e = hipMalloc((void**)&fa, (size_t)max_nodes * sizeof(WideItem))) != hipSuccess
+	    || (e = hipMalloc((void**)&fb, (size_t)max_nodes * sizeof(WideItem))) != hipSuccess || (e = hipMalloc((void**)&ctr, 16)) != hipSuccess || (e = hipMalloc((void**)&fail, 16)) != hipSuccess)
+		return bail(e);
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	hipEventRecord(e0, stream);
+	hipMemsetAsync(q4, 0, (size_t)max_nodes * 64, stream);
+	hipMemsetAsync(fail, 0, 16, stream);
+	const WideItem rootItem = { 0, 0u };
+	unsigned int h_ctr[2] = { 1u, 0u };
+	hipMemcpyAsync(fa, &rootItem, sizeof(rootItem), hipMemcpyHostToDevice, stream);
+	int n_items = 1, levels = 0; int h_fail = 0;
+	WideItem *cur = fa, *nxt = fb;
+	while (n_items > 0 && levels < 64)
+	{
+		hipMemcpyAsync(ctr, h_ctr, 8, hipMemcpyHostToDevice, stream);
+		hipLaunchKernelGGL(k_q4_level, dim3((n_items + 63) / 64), dim3(64), 0, stream, nodes, (const WideItem*)cur, n_items, q4, ctr, nxt, ctr + 1, max_nodes, fail);
+		hipMemcpyAsync(h_ctr, ctr, 8, hipMemcpyDeviceToHost, stream);
+		hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, stream);
+		if ((e = hipStreamSynchronize(stream)) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return bail(e); }
+		levels++;
+		if (h_fail) break;
+		n_items = (int)h_ctr[1]; h_ctr[1] = 0u;
+		std::swap(cur, nxt);
+	}
+	hipEventRecord(e1, stream); hipStreamSynchronize(stream);
+	hipEventElapsedTime(&r.build_ms, e0, e1); hipEventDestroy(e0); hipEventDestroy(e1);
+	hipFree(fa); hipFree(fb); hipFree(ctr); hipFree(fail);
+	if (h_fail || levels >= 64) { hipFree(q4); return hipSuccess; }
+	r.d_wide = q4; r.n_wide = (int)h_ctr[0]; r.height = levels;
+	return hipSuccess;
+}
 #endif

@@ -336,9 +336,13 @@ public:
 	FlatBVH bvh;                                                 // built by Preprocess() unless deviceBuild
 	bool preprocessed = false;
 	// true: Preprocess() skips the host SAH build and the flattened scene carries no hierarchy (n_bvh_nodes = 0), so
-	// jp_upload_scene builds an LBVH on the device.  Setup drops from ~0.3 s to a few ms on the 280k-triangle scene at
-	// the price of a lower-quality tree: meant for previews / low spp.  Default from env JETPBRT_DEVICE_BVH=1.
-	bool deviceBuild = false;
+	// jp_upload_scene builds the tree on the device (round 3: PLOC clustering, jp_ploc.h -- as fast to walk as the host's binned-SAH
+	// tree on the 280k-triangle scene, setup 0.2 s -> 0.06 s; rounds 1-2: an LBVH, 7-18 % slower to walk).
+	// Default (round 3): scenes of more than kDeviceBuildFrom primitives build on the device, smaller ones on the host (their trees
+	// become flat leaf lists / LDS-resident trees, which need the host's leaves).  hostBuild = true or env JETPBRT_DEVICE_BVH=0 keep the
+	// host build for every scene, deviceBuild = true or JETPBRT_DEVICE_BVH=1 force the device build.
+	bool deviceBuild = false, hostBuild = false;
+	static constexpr size_t kDeviceBuildFrom = 4096;
 	// true: Preprocess() builds the reference's own tree (BuildReferenceBVH: its rand() sequence from the default seed, its
 	// std::sort, median split, leaves <= 5, over the reference's WorldBounds) and the flattened scene asks the device to walk
 	// it with the reference's semantics (JpScene.bvh_reference_semantics): the film then equals the reference's bit for bit on

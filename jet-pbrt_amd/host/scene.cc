@@ -235,7 +235,9 @@ void FScene::Preprocess()                                                // scen
 		preprocessed = true;
 		return;
 	}
-	if (const char* e = getenv("JETPBRT_DEVICE_BVH")) if (atoi(e) == 1) deviceBuild = true;
+	bool dev = deviceBuild || (!hostBuild && primitives.size() > kDeviceBuildFrom);
+	if (const char* e = getenv("JETPBRT_DEVICE_BVH")) dev = atoi(e) == 1 ? true : (atoi(e) == 0 ? false : dev);
+	deviceBuild = dev;
 	if (deviceBuild) { bvh = FlatBVH(); preprocessed = true; return; }
 	std::vector<FBounds3> pb; pb.reserve(primitives.size());
 	// own BVH over the exact extents: a ray leaving a flat surface (min_t 0.001) or ending 0.001 short of a light

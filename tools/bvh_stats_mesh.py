@@ -11,7 +11,8 @@ def arr(p, n, shape=None):
     return a if shape is None else a.reshape(shape)
 
 W = Hh = 64
-hb = H.scenes.build_bunny(H.scenes.HostBackend("st"), W, Hh)
+hb = H.scenes.HostBackend("st"); hb.set_device_build(False)      # the host SAH tree is what this tool walks
+H.scenes.build_bunny(hb, W, Hh)
 sp = hb.flatten(); s = sp.contents
 left = arr(s.bvh_left, s.n_bvh_nodes); right = arr(s.bvh_right, s.n_bvh_nodes); bnd = arr(s.bvh_bounds, 6 * s.n_bvh_nodes, (-1, 6))
 pidx = arr(s.bvh_prim_index, s.n_bvh_prim_indices)
