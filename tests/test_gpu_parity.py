@@ -1144,3 +1144,52 @@ def test_four_wide_quantised_tree_hit_records_and_film(H, monkeypatch):
             c.close()
         assert np.array_equal(film.view(np.uint32), film4.view(np.uint32)), env
         assert (cnt.closest_rays, cnt.closest_hits, cnt.shadow_rays, cnt.shadow_occluded) == (cnt4.closest_rays, cnt4.closest_hits, cnt4.shadow_rays, cnt4.shadow_occluded), env
+
+
+def test_device_build_ploc_and_lbvh_topologies_and_the_default_by_scene_size(H, monkeypatch):
+    """round 3: the device builds its hierarchy by PLOC clustering (csrc/jp_ploc.h) and collapses it into the 4-wide tree on the device;
+    JETPBRT_DEVICE_TREE=lbvh keeps the Karras topology.  On a 12k-triangle mesh scene: both give hit records bit-exact against the oracle
+    (axis-parallel rays included) and films within the gate of each other and of the host-built tree; scenes of more than 4096 primitives
+    build on the device BY DEFAULT (FScene::Preprocess), JETPBRT_DEVICE_BVH=0 / set_device_build(False) keep the host's SAH tree"""
+    W, Hh, spp = 128, 96, 8
+    def scene(mode):
+        hb = H.scenes.HostBackend("ploc")
+        if mode is not None:
+            hb.set_device_build(mode)
+        H.scenes.build_bunny(hb, W, Hh, n_lon=40, n_lat=38)
+        return hb, hb.flatten()
+    hb_auto, sp_auto = scene(None)
+    assert sp_auto.contents.n_primitives > 4096 and sp_auto.contents.n_bvh_nodes == 0          # default: no host hierarchy for a scene this size
+    hb_host, sp_host = scene(False)
+    assert sp_host.contents.n_bvh_nodes > 0
+    monkeypatch.setenv("JETPBRT_DEVICE_BVH", "0")
+    hb_env, sp_env = scene(None)
+    monkeypatch.delenv("JETPBRT_DEVICE_BVH")
+    assert sp_env.contents.n_bvh_nodes > 0
+    rng = np.random.default_rng(23)
+    m = 100000
+    o = (rng.random((m, 3)) * [500, 300, 500] - [250, -10, 250]).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[: m // 50, 0] = 0.0; d[m // 50: m // 25, 1] = 0.0
+    tmin = np.full(m, 0.001, np.float32); tmax = np.where(rng.random(m) < 0.5, np.inf, rng.random(m) * 400).astype(np.float32)
+    ohit, ot, oprim, onrm = _oracle_trace(H, sp_auto, o, d, tmin, tmax)
+    films = {}
+    for tag, sp, env in (("ploc", sp_auto, {}), ("lbvh", sp_auto, {"JETPBRT_DEVICE_TREE": "lbvh"}), ("host", sp_host, {})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = H.jp.Context(0)
+        try:
+            ctx.upload(sp)
+            bi = ctx.build_info()
+            assert bi.built_on_device == (0 if tag == "host" else 1) and bi.q4_nodes > 1000 and bi.traversal_mode == 3, tag
+            hit, t, prim, nrm = ctx.trace(o, d, tmin, tmax)
+            assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)), tag
+            assert (prim == oprim).mean() > 0.9999, tag
+            films[tag] = ctx.render(H.jp.render_params(W, Hh, spp, 5, 3))
+        finally:
+            ctx.close()
+            for k in env:
+                monkeypatch.delenv(k)
+    assert l2(films["ploc"], films["host"]) < TOL_L2 and l2(films["lbvh"], films["host"]) < TOL_L2
+    ref, _ = H.oracle_render(sp_auto, H.jp.render_params(W, Hh, spp, 5, 3), len(os.sched_getaffinity(0)))
+    assert l2(films["ploc"], ref) < TOL_L2
