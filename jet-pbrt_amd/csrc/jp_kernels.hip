@@ -1946,12 +1946,14 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		if (e == hipSuccess) e = hipMemcpyAsync(d_p0, prims.data(), prims.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream);
 		if (e == hipSuccess) e = hipMemcpyAsync(d_m0, meta.data(), meta.size() * sizeof(int4), hipMemcpyHostToDevice, c->stream);
 		LbvhResult lr; std::vector<int> sorted;
-		int maxLeaf = 3;                                            // measured on the 280k-triangle scene: 540 / 578 / 579 / 560 / 534 / 497 Msamples/s for 1 / 2 / 3 / 4 / 6 / 8
+		// leaf size: LBVH 3 (round 1, 280k-triangle scene: 540 / 578 / 579 / 560 / 534 / 497 Msamples/s for 1 / 2 / 3 / 4 / 6 / 8); PLOC 2 (round 3, with the 4-wide
+		// tree: k_extend 28.0 / 25.3 / 26.1 / 27.1 ms and k_shadow 21.7 / 19.8 / 20.5 / 21.6 ms per 256 spp for 1 / 2 / 3 / 4, profiles/r03g_ploc_ab.txt)
+		bool ploc = true;
+		if (const char* ev = getenv("JETPBRT_DEVICE_TREE")) ploc = std::string(ev) != "lbvh";
+		int maxLeaf = ploc ? 2 : 3;
 		if (const char* ev = getenv("JETPBRT_BVH_MAXLEAF")) { int v = atoi(ev); if (v >= 1 && v <= 16) maxLeaf = v; }
 		// [round 3] PLOC clustering (jp_ploc.h) instead of the Karras topology; JETPBRT_DEVICE_TREE=lbvh restores the latter, which also serves
 		// as the fallback should the clustering not finish within its round limit
-		bool ploc = true;
-		if (const char* ev = getenv("JETPBRT_DEVICE_TREE")) ploc = std::string(ev) != "lbvh";
 		if (e == hipSuccess && ploc) { e = ploc_build(c->stream, (const float4*)d_p0, (const int4*)d_m0, s->n_primitives, maxLeaf, lr, sorted); if (e == hipErrorNotReady) { e = hipSuccess; ploc = false; } }
 		if (e == hipSuccess && !ploc) e = lbvh_build(c->stream, (const float4*)d_p0, (const int4*)d_m0, s->n_primitives, maxLeaf, lr, sorted);
 		if (d_p0) hipFree(d_p0); if (d_m0) hipFree(d_m0);

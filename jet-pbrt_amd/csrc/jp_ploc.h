@@ -94,13 +94,13 @@ __device__ __forceinline__ float ploc_union_area(const PlocCluster& a, const Plo
 }
 // nearest neighbour within the window: least area of the union box; ties go to the partner i ^ 1, then to the nearer position, then to the
 // smaller one -- a symmetric rule, so coincident primitives still pair up (0-1, 2-3, ...) instead of merging one pair per round
-__global__ void __launch_bounds__(256) k_ploc_nn(const PlocCluster* __restrict__ c, int m, int* __restrict__ nn)
+__global__ void __launch_bounds__(256) k_ploc_nn(const PlocCluster* __restrict__ c, int m, int radius, int* __restrict__ nn)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= m) return;
 	const PlocCluster me = c[i];
 	float bestA = 3.0e38f; int best = -1, bestRank = 0x7fffffff;
-	const int j0 = max(0, i - JP_PLOC_RADIUS), j1 = min(m - 1, i + JP_PLOC_RADIUS);
+	const int j0 = max(0, i - radius), j1 = min(m - 1, i + radius);
 	for (int j = j0; j <= j1; j++)
 	{
 		if (j == i) continue;
@@ -240,13 +240,15 @@ static hipError_t ploc_build(hipStream_t stream, const float4* prims0, const int
 	lbvh_sort(stream, keys, keys2, vals, vals2, n, (unsigned int*)sorttmp);
 	hipLaunchKernelGGL(k_lbvh_gather, dim3(grid), dim3(256), 0, stream, (const int*)vals2, n, prims0, meta0, (const float4*)lo0, (const float4*)hi0, primsS, metaS, lo, hi);
 	hipLaunchKernelGGL(k_ploc_init, dim3(grid), dim3(256), 0, stream, (const float4*)lo, (const float4*)hi, n, ca);
+	int radius = JP_PLOC_RADIUS;                                   // measured on the 280k-triangle scene (profiles/r03g_ploc_ab.txt)
+	if (const char* ev = getenv("JETPBRT_PLOC_RADIUS")) { const int v = atoi(ev); if (v >= 1 && v <= 256) radius = v; }
 	int m = n, next_id = 0, rounds = 0;
 	bool stuck = false;
 	while (m > 1)
 	{
 		if (++rounds > 512) { stuck = true; break; }
 		const int g = (m + 255) / 256, nb = (m + 1023) / 1024;
-		hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(256), 0, stream, (const PlocCluster*)ca, m, nn);
+		hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(256), 0, stream, (const PlocCluster*)ca, m, radius, nn);
 		hipLaunchKernelGGL(k_ploc_flags, dim3(g), dim3(256), 0, stream, (const int*)nn, m, flags);
 		hipLaunchKernelGGL(k_scan2_block, dim3(nb), dim3(256), 0, stream, (const uint2*)flags, scan, m, tops);
 		hipLaunchKernelGGL(k_scan2_tops, dim3(1), dim3(256), 0, stream, tops, nb, total);
