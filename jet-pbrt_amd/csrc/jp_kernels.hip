@@ -1639,11 +1639,14 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	// ---- device primitive records in leaf order + device BVH (children boxes in the parent) ----
 	std::vector<int> hostToDevNode(s->n_bvh_nodes, -1), devPrimOf(s->n_primitives, -1);
 	std::vector<float4> nodes; std::vector<float4> prims; std::vector<int4> meta;
+	// JETPBRT_BOX_PAD (diagnosis only, tools/gpu_fringe_census.py): every box of the host-built trees grows by this many scene units, so the walk
+	// also visits the leaves whose triangles accept a hit in the fp32 fringe OUTSIDE their exact box -- a stand-in for testing every primitive
+	float extra_pad = 0.f; if (const char* ev = getenv("JETPBRT_BOX_PAD")) extra_pad = std::max(0.f, (float)atof(ev));
 	auto pad_box = [&](int n, float* b) {
 		for (int a = 0; a < 3; a++)
 		{
 			float lo = s->bvh_bounds[6 * n + a], hi = s->bvh_bounds[6 * n + 3 + a];
-			float m = std::max(std::fabs(lo), std::fabs(hi)); float e = m * 1e-6f + 1e-6f;   // >> ulp(m): flat (zero-extent) boxes stay hittable
+			float m = std::max(std::fabs(lo), std::fabs(hi)); float e = m * 1e-6f + 1e-6f + extra_pad;   // >> ulp(m): flat (zero-extent) boxes stay hittable
 			b[a] = lo - e; b[3 + a] = hi + e;
 		}
 	};
