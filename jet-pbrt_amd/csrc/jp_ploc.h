@@ -242,11 +242,13 @@ static hipError_t ploc_build(hipStream_t stream, const float4* prims0, const int
 	hipLaunchKernelGGL(k_ploc_init, dim3(grid), dim3(256), 0, stream, (const float4*)lo, (const float4*)hi, n, ca);
 	int radius = JP_PLOC_RADIUS;                                   // measured on the 280k-triangle scene (profiles/r03g_ploc_ab.txt)
 	if (const char* ev = getenv("JETPBRT_PLOC_RADIUS")) { const int v = atoi(ev); if (v >= 1 && v <= 256) radius = v; }
+	int max_rounds = 512;                                          // ~40 rounds for 280k primitives; the limit guards against a build that does not converge
+	if (const char* ev = getenv("JETPBRT_PLOC_MAX_ROUNDS")) { const int v = atoi(ev); if (v >= 1) max_rounds = v; }   // (test hook: forces the LBVH fallback)
 	int m = n, next_id = 0, rounds = 0;
 	bool stuck = false;
 	while (m > 1)
 	{
-		if (++rounds > 512) { stuck = true; break; }
+		if (++rounds > max_rounds) { stuck = true; break; }
 		const int g = (m + 255) / 256, nb = (m + 1023) / 1024;
 		hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(256), 0, stream, (const PlocCluster*)ca, m, radius, nn);
 		hipLaunchKernelGGL(k_ploc_flags, dim3(g), dim3(256), 0, stream, (const int*)nn, m, flags);

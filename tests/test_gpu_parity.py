@@ -1174,7 +1174,8 @@ def test_device_build_ploc_and_lbvh_topologies_and_the_default_by_scene_size(H, 
     tmin = np.full(m, 0.001, np.float32); tmax = np.where(rng.random(m) < 0.5, np.inf, rng.random(m) * 400).astype(np.float32)
     ohit, ot, oprim, onrm = _oracle_trace(H, sp_auto, o, d, tmin, tmax)
     films = {}
-    for tag, sp, env in (("ploc", sp_auto, {}), ("lbvh", sp_auto, {"JETPBRT_DEVICE_TREE": "lbvh"}), ("host", sp_host, {})):
+    for tag, sp, env in (("ploc", sp_auto, {}), ("lbvh", sp_auto, {"JETPBRT_DEVICE_TREE": "lbvh"}), ("host", sp_host, {}),
+                         ("fallback", sp_auto, {"JETPBRT_PLOC_MAX_ROUNDS": "3"})):      # the clustering gives up after 3 rounds -> the LBVH topology serves
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ctx = H.jp.Context(0)
@@ -1191,5 +1192,6 @@ def test_device_build_ploc_and_lbvh_topologies_and_the_default_by_scene_size(H, 
             for k in env:
                 monkeypatch.delenv(k)
     assert l2(films["ploc"], films["host"]) < TOL_L2 and l2(films["lbvh"], films["host"]) < TOL_L2
+    assert np.array_equal(films["fallback"].view(np.uint32), films["lbvh"].view(np.uint32))
     ref, _ = H.oracle_render(sp_auto, H.jp.render_params(W, Hh, spp, 5, 3), len(os.sched_getaffinity(0)))
     assert l2(films["ploc"], ref) < TOL_L2
