@@ -2228,7 +2228,7 @@ struct Stamper
 	~Stamper() { if (!c->profiling) return; hipEventRecord(c->evpool[a + 1], st); JpContext::Stamp s = { cls, a, a + 1 }; c->stamps.push_back(s); }
 };
 
-int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sync, int lane_index = 0, int lane_count = 1, int lane_group = 4)
+int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sync, int lane_index = 0, int lane_count = 1, int lane_group = 4, bool ev0_recorded = false)
 {
 	if (!c || !rp || !film_dev) return fail(JP_ERR_INVALID_ARGUMENT, "jp_render: null argument");
 	if (!c->have_scene) return fail(JP_ERR_NO_SCENE, "jp_render: no scene uploaded");
@@ -2253,7 +2253,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 	}
 	const long long npix = (long long)local_rows * rp->width;
 
-	HIP_TRY(hipEventRecord(c->ev0, c->stream));
+	if (!ev0_recorded) HIP_TRY(hipEventRecord(c->ev0, c->stream));          // (with several lanes render_impl records it before the first lane is enqueued)
 	HIP_TRY(hipMemsetAsync(film_dev, 0, sizeof(float) * 3 * (size_t)rp->width * rp->height, c->stream));
 	HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(DevCounters), c->stream));
 	c->evused = 0; c->stamps.clear();
@@ -2379,6 +2379,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 					else JP_LAUNCH_SHADE(false, false, false);
 					#undef JP_LAUNCH_SHADE
 				}
+				HIP_TRY(hipGetLastError());                               // a failed launch (k_extend / k_shade) is reported where it happens, not at the end of the frame
 				if (it < rp->max_depth || c->has_null_material)                 // at bounce == maxDepth Li() breaks before the NEE (integrator.cc:340-343)
 				{
 					const bool two = c->dual && c->persist && c->stream2 && !c->has_null_material;
@@ -2409,6 +2410,7 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 					else if (c->trav_mode == 1) hipLaunchKernelGGL(k_shadow<1>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 					else hipLaunchKernelGGL(k_shadow<0>, dim3(grid), dim3(JP_BLOCK), lds, c->stream, c->sv, c->q, rc, c->stack_depth, c->d_cnt);
 					if (two) { HIP_TRY(hipEventRecord(c->ev_shadow, c->stream2)); shadow_pending = true; }
+					HIP_TRY(hipGetLastError());
 				}
 				cur ^= 1;
 			}
@@ -2662,6 +2664,7 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 	const size_t n = (size_t)rp->width * rp->height * 3;
 	// workgroups per CU and lane (measured on the benchmark frame, two lanes: 2.51 Gsamples/s at 16 + 16, 2.70 at 8 + 8,
 	// 2.74 at 6 + 6, 2.60 at 4 + 4; three lanes: 2.83 at 5 + 5 + 5; a single lane is best at 16)
+	HIP_TRY(hipEventRecord(c->ev0, c->stream));                                       // render_ms starts before the first lane's kernels are enqueued
 	const int bpc_single = c->blocks_per_cu, bpc_lane = c->bpc_from_env ? c->blocks_per_cu : std::max(4, 16 / L);
 	for (int k = 1; k < L && st == JP_OK; k++)
 	{
@@ -2672,7 +2675,7 @@ int render_impl(JpContext* c, const JpRenderParams* rp, float* film_dev, bool sy
 		l->blocks_per_cu = bpc_lane;
 		st = render_one(l, rp, l->d_film, false, k, L, group);
 	}
-	if (st == JP_OK) { c->blocks_per_cu = bpc_lane; st = render_one(c, rp, film_dev, false, 0, L, group); c->blocks_per_cu = bpc_single; }
+	if (st == JP_OK) { c->blocks_per_cu = bpc_lane; st = render_one(c, rp, film_dev, false, 0, L, group, true); c->blocks_per_cu = bpc_single; }
 	if (st != JP_OK) return st;
 	for (int k = 1; k < L; k++)
 	{
