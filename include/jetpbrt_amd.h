@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define JP_ABI_VERSION 5
+#define JP_ABI_VERSION 6
 
 typedef enum JpStatus {
     JP_OK = 0,
@@ -104,7 +104,13 @@ typedef struct JpScene {
      * 1: REFERENCE SEMANTICS -- the given tree is walked node for node the way FBVH_Node::Intersect does (bvh.h:94-103: box
      *    test of geometry.cc:10-30 with its `tmax <= tmin` rejection on the unpadded bounds, left subtree then right, leaf
      *    objects in order).  With the reference's own tree (host: FScene::referenceTree) the hits are then the reference's hits
-     *    even where those depend on its topology (finely tessellated meshes, DESIGN.md "Numerics").  Several times slower. */
+     *    even where those depend on its topology (finely tessellated meshes, DESIGN.md "Numerics").  Several times slower.
+     * 2: (ABI 6) REFERENCE SEMANTICS, CERTIFIED WALK -- scenes of more than 1024 primitives: the rays take an ordered walk over the LEAVES
+     *    of the given tree; each result carries a proof that the walk of (1) returns the same hit (FBounds3::Intersect on the hit's leaf
+     *    box with max_t = the hit distance implies the same for every ancestor and every larger max_t), and the rays without a proof are
+     *    walked again as in (1).  About twice as fast as (1).  Not strictly identical to (1): a ray within fp32 noise of a triangle's
+     *    plane is accepted or not by the signs of rounding errors, wherever along the ray that triangle lies, and only (1) visits all of
+     *    those (DESIGN.md "Certified walk": about one camera ray in 10^6 on the 280k-triangle scene).  Smaller scenes: as (1). */
     int32_t bvh_reference_semantics;
 
     /* FDisk (shape.h:189-275): position, normal (already normalised by the constructor, shape.h:194), radius */
@@ -138,6 +144,9 @@ typedef struct JpCounters {
      * When it runs, extend_ms / shade_ms / shadow_ms stay 0 and path_ms is the sum of the k_path launches. */
     double   path_ms;
     uint64_t path_launches;
+    /* ABI 6: reference semantics with the certified walk (JpBuildInfo.certified_walk): rays (closest-hit and shadow) whose result the
+     * ordered walk could not certify and which were walked again node for node the reference's way */
+    uint64_t certified_fallback_rays;
 } JpCounters;
 
 /* what jp_upload_scene did with the hierarchy */
@@ -157,6 +166,10 @@ typedef struct JpBuildInfo {
                                     and reference-semantics trees, JETPBRT_Q4=0) */
     int32_t libm_xbsdf;          /* ABI 5: bit 0: the device reproduces the host libm's logf / expf / powf / acosf / atanf / tanf bit for bit (the BSDF
                                     classes behind jp_bsdf that call them are then bit-exact against the reference); bit 1: with libm's FMA build */
+    int32_t certified_walk;      /* ABI 6: bvh_reference_semantics on a large scene: 1 = the rays take an ordered walk over the LEAVES of the caller's tree and
+                                    carry a proof that FBVH_Node::Intersect returns the same hit; the few that cannot are walked again verbatim
+                                    (DESIGN.md "Certified walk"; JETPBRT_CERTIFIED=0: every ray verbatim, as in ABI <= 5) */
+    int32_t certified_nodes;     /* nodes of the 4-wide tree over the caller's leaves */
 } JpBuildInfo;
 
 typedef struct JpContext JpContext;

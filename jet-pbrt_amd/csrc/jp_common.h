@@ -18,6 +18,7 @@ struct DevCounters
 	unsigned int n_shadow;
 	unsigned int pad;
 	unsigned long long closest, closest_hit, shadow, shadow_occ;
+	unsigned long long cert_fallback;          // Walker<6>: rays walked again the reference's way
 };
 
 struct Queues

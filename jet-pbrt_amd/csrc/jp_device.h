@@ -70,6 +70,7 @@ struct SceneView
 	const uint4* wide; int n_wide;          // large scenes: 8-wide quantised nodes, 5 x 16 bytes each (traverse_wide)
 	const float4* cut; int n_cut;           // other than tiny scenes: boxes of the <= 16 largest subtrees below the root in the flat_boxes layout (one bit each): the sort key of k_extend_sort / k_shadow_sort
 	const uint4* q4; int n_q4;              // large scenes: 4-wide tree with quantised child boxes, 4 x 16 bytes per node (Walker<4>)
+	const float4* refbox; float cert_pad;   // reference semantics, certified walk (Walker<6>): per device primitive the exact box of its leaf in the caller's tree (min, max); distance-cull slack c in tmax + c * tmax^2
 };
 
 // ---- shape intersection: exact restatements ---------------------------------------------------------------------
@@ -585,12 +586,33 @@ template <> struct Walker<3>
 // distances: each hit child's rank among the hits (six comparisons) says where it goes -- rank 0 is walked next, the others onto the
 // stack, farthest first.  Half the node steps per ray of the binary walk for the same bytes per step.  The quantised boxes contain
 // the binary tree's boxes, so every hit the binary walk finds is found (never a dropped hit; fringe hits as DESIGN.md "Numerics").
-template <> struct Walker<4>
+//
+// kCert (Walker<6>, reference semantics on large scenes): the CERTIFIED walk.  The 4-wide tree is then built over the LEAVES of the caller's
+// (the reference's) tree -- one leaf of this tree = one leaf of that tree, its objects tested in that leaf's order -- and the ordered walk
+// is used to find the closest accepted hit among all leaves the reference could visit, together with a proof that the reference finds
+// exactly that hit:
+//  * the reference reaches a leaf only through FBounds3::Intersect of the leaf's own box (bvh.h:94-103, the node that wraps the leaf), so the
+//    leaves that can contribute are those whose box the ray passes; this walk's boxes contain them (quantised outward), and a node is
+//    culled by distance only beyond tmax + cert_pad * tmax^2 (a hit accepted in the fp32 fringe just IN FRONT of its leaf's box lies
+//    nearer than the box entry; the slack is the part of this scheme that is empirical, DESIGN.md "Certified walk");
+//  * for the closest hit found, (t, p): if the box test of geometry.cc:10-30, verbatim, passes on p's leaf box with max_t = t, it passes
+//    on that box and on every ancestor's (their planes enclose it; correctly rounded subtraction and division are monotone) for every
+//    max_t >= t -- and the reference's max_t never drops below t before it reaches the leaf, because no accepted hit is nearer.  So the
+//    reference visits the leaf and accepts p.  `certain()` evaluates exactly that;
+//  * two accepted hits at the same distance (the reference keeps whichever it reaches first), a certificate that fails, a ray parallel to
+//    an axis: the ray is UNSURE and is walked again the reference's way (Walker<5>) -- a few rays in 10^4.
+// Shadow rays: any accepted hit with a passing certificate means the reference's walk ends occluded; none found means visible.
+template <bool kCert> struct WalkerQ4
 {
-	V3 o, d; float ix, iy, iz, tmin, tmax; int cur, sp, hit; bool done;
+	V3 o, d; float ix, iy, iz, tmin, tmax; int cur, sp, hit; bool done, unsure;
 	__device__ __forceinline__ void start(V3 o_, V3 d_, float tmin_, float tmax_)
-	{ o = o_; d = d_; ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z; tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; done = false; }
+	{ o = o_; d = d_; ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z; tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; done = false; unsure = kCert && (d.x == 0.f || d.y == 0.f || d.z == 0.f); }
 	__device__ __forceinline__ bool heavy() const { return cur < 0; }                 // next step is a leaf (primitive tests), not a node
+	// FBounds3::Intersect (geometry.cc:10-30) on the reference leaf box of primitive p with max_t = t
+	__device__ __forceinline__ bool leaf_box_passes(const SceneView& sc, int p, float t) const
+	{ const float4 b0 = sc.refbox[2 * (size_t)p], b1 = sc.refbox[2 * (size_t)p + 1]; return ref_box_exact(b0, b1, o, d, tmin, t); }
+	// closest hit: is (tmax, hit) what the reference returns?  (any-hit rays are decided as they go: hit >= 0 is certain, unsure says the rest)
+	__device__ __forceinline__ bool certain(const SceneView& sc) const { return !unsure && (hit < 0 || leaf_box_passes(sc, hit, tmax)); }
 	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, const WalkStack& stack)
 	{
 		bool pop = true;
@@ -610,6 +632,7 @@ template <> struct Walker<4>
 			const unsigned int ayn = ny ? q2.y : q3.x, ayf = ny ? q3.x : q2.y;
 			const unsigned int azn = nz ? q2.z : q3.y, azf = nz ? q3.y : q2.z;
 			float tn[4]; bool hc[4]; int nh = 0;
+			const float tcull = kCert ? fmaf(sc.cert_pad * tmax, tmax, tmax) : tmax;
 			#pragma unroll
 			for (int i = 0; i < 4; i++)
 			{
@@ -618,7 +641,7 @@ template <> struct Walker<4>
 				const float y0 = fmaf((float)((ayn >> sh) & 0xffu), ay, by), y1 = fmaf((float)((ayf >> sh) & 0xffu), ay, by);
 				const float z0 = fmaf((float)((azn >> sh) & 0xffu), az, bz), z1 = fmaf((float)((azf >> sh) & 0xffu), az, bz);
 				const float t0 = fmaxf(fmaxf(x0, y0), fmaxf(z0, tmin));
-				const float tf = fminf(fminf(x1, y1), fminf(z1, tmax));
+				const float tf = fminf(fminf(x1, y1), fminf(z1, tcull));
 				hc[i] = ((q0.w >> (24 + i)) & 1u) && t0 <= tf * 1.000002f;
 				tn[i] = hc[i] ? fminf(t0, 3.0e38f) : JP_INF;             // a missed child ranks behind every hit one
 				nh += hc[i] ? 1 : 0;
@@ -660,21 +683,51 @@ template <> struct Walker<4>
 		else
 		{   // one leaf per step (Walker<0>)
 			const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
+			if (kCert)
+			{
+				for (int k = 0; k < count; k++)
+				{
+					// accept distance <= tmax to see ties: prim_hit's `distance < bound` with the next float above tmax as the bound (inf stays inf)
+					float tm = __int_as_float(__float_as_int(tmax) + (tmax < JP_INF ? 1 : 0));
+					if (!prim_hit<4>(sc.prims, first + k, o, d, tmin, tm)) continue;
+					if (kAnyHit)
+					{
+						if (!(tm < tmax)) continue;                                       // distance == max_t: not a hit for the reference either
+						if (leaf_box_passes(sc, first + k, tm)) { hit = first + k; done = true; return; }
+						unsure = true;                                                    // accepted, but the reference may never reach this leaf: go on looking
+					}
+					else if (tm < tmax) { tmax = tm; hit = first + k; }
+					else if (hit >= 0) unsure = true;                                     // a second primitive at exactly the closest distance
+				}
+			}
+			else
 			for (int k = 0; k < count; k++)
 				if (prim_hit<4>(sc.prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) { done = true; return; } }
 		}
 		if (pop) { if (sp > 0) { sp--; cur = stack.get(sp); } else done = true; }
 	}
 };
+template <> struct Walker<4> : WalkerQ4<false> {};
+template <> struct Walker<6> : WalkerQ4<true> {};
 
 // a walker driven to the end by one lane (k_trace, k_other): the same steps as under lane refill
 template <int kMode, bool kAnyHit>
 __device__ __forceinline__ int walk_ray(const SceneView& sc, V3 o, V3 d, float tmin, float& tmax, const WalkStack& stack)
 {
-	Walker<kMode> w; w.start(o, d, tmin, tmax);
-	while (!w.done) w.template step<kAnyHit>(sc, stack);
-	tmax = w.tmax;
-	return w.hit;
+	if constexpr (kMode == 6)
+	{   // certified walk; an unsure ray is walked again the reference's way
+		Walker<6> w; w.start(o, d, tmin, tmax);
+		while (!w.done) w.template step<kAnyHit>(sc, stack);
+		if (kAnyHit ? (w.hit >= 0 || !w.unsure) : w.certain(sc)) { tmax = w.tmax; return w.hit; }
+		return walk_ray<5, kAnyHit>(sc, o, d, tmin, tmax, stack);
+	}
+	else
+	{
+		Walker<kMode> w; w.start(o, d, tmin, tmax);
+		while (!w.done) w.template step<kAnyHit>(sc, stack);
+		tmax = w.tmax;
+		return w.hit;
+	}
 }
 
 } // namespace jp

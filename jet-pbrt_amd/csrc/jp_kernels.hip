@@ -211,6 +211,14 @@ template <> struct SceneAccess<4>
 	{ return walk_ray<4, kAnyHit>(sc, o, d, tmin, tmax, stack); }
 };
 
+template <> struct SceneAccess<6>
+{   // reference semantics, certified walk (Walker<6>) with the verbatim walk behind it for the rays it cannot certify (k_trace)
+	WalkStack stack;
+	__device__ __forceinline__ SceneAccess(const SceneView&, int depth) { stack.lds = (int*)s_dyn + threadIdx.x; stack.spill = nullptr; stack.cap = depth - 1; stack.stride = 0; }
+	template <bool kAnyHit> __device__ __forceinline__ int trace(const SceneView& sc, V3 o, V3 d, float tmin, float& tmax) const
+	{ return walk_ray<6, kAnyHit>(sc, o, d, tmin, tmax, stack); }
+};
+
 template <> struct SceneAccess<5>
 {
 	const float4 *nodes, *prims; int* stack;
@@ -817,7 +825,7 @@ template <int kMode, int kRefill, bool kVote>
 __global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queues q, int cur_q, int stack_cap, int* spill, DevCounters* cnt)
 {
 	__shared__ unsigned int s_next;
-	const WalkStack stack = { (int*)s_dyn + threadIdx.x, spill + blockIdx.x * JP_BLOCK + threadIdx.x, kMode == 4 ? stack_cap - 1 : stack_cap, gridDim.x * JP_BLOCK };   // Walker<4>: the last LDS word is its dump slot
+	const WalkStack stack = { (int*)s_dyn + threadIdx.x, spill + blockIdx.x * JP_BLOCK + threadIdx.x, (kMode == 4 || kMode == 6) ? stack_cap - 1 : stack_cap, gridDim.x * JP_BLOCK };   // Walker<4> / <6>: the last LDS word is the dump slot
 	const unsigned int b = blockIdx.x, n = q.blk_q[cur_q][b], rbase = b * q.R;
 	if (b == 0 && threadIdx.x == 0) { cnt->closest += cnt->n_queue[cur_q]; cnt->n_queue[cur_q ^ 1] = 0; cnt->n_shadow = 0; }
 	if (threadIdx.x == 0) s_next = 0;
@@ -833,7 +841,12 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queue
 		const int nidle = __popcll(idle);
 		if (nidle == 64 || (pool && nidle >= kRefill))
 		{
-			if (w.done && ridx != 0xffffffffu) { q.hit[rbase + ridx] = make_float2(w.tmax, __int_as_float(w.hit)); h += w.hit >= 0 ? 1u : 0u; ridx = 0xffffffffu; }
+			if (w.done && ridx != 0xffffffffu)
+			{
+				int hp = w.hit;
+				if constexpr (kMode == 6) { if (!w.certain(sc)) hp = -2; }   // not certified: marked, walked again below the reference's way
+				q.hit[rbase + ridx] = make_float2(w.tmax, __int_as_float(hp)); h += hp >= 0 ? 1u : 0u; ridx = 0xffffffffu;
+			}
 			if (!pool) break;                                        // every lane idle, nothing left
 			const int first = __ffsll((long long)idle) - 1;
 			unsigned int start = 0;
@@ -859,6 +872,19 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queue
 			if (!w.done && (w.heavy() == heavyTurn)) w.template step<false>(sc, stack);
 		}
 	}
+	if constexpr (kMode == 6)
+	{   // the marked rays (a few in 10^4), FBVH_Node::Intersect's own walk
+		__syncthreads();
+		for (unsigned int i = threadIdx.x; i < n; i += JP_BLOCK)
+		{
+			if (__float_as_int(q.hit[rbase + i].y) != -2) continue;
+			const float4 ro = q.ray_o[cur_q][rbase + i], rd = q.ray_d[cur_q][rbase + i];
+			float tm = JP_INF;
+			const int hp = walk_ray<5, false>(sc, xyz(ro), xyz(rd), 0.001f, tm, stack);
+			q.hit[rbase + i] = make_float2(tm, __int_as_float(hp)); h += hp >= 0 ? 1u : 0u;
+			if (cnt) atomicAdd(&cnt->cert_fallback, 1ull);
+		}
+	}
 	for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off);
 	if (lane == 0 && h) atomicAdd(&cnt->closest_hit, (unsigned long long)h);
 }
@@ -867,11 +893,12 @@ template <int kMode, int kRefill, bool kVote>
 __global__ void __launch_bounds__(JP_BLOCK) k_shadow_persist(SceneView sc, Queues q, RenderConst rc, int stack_cap, int* spill, DevCounters* cnt)
 {
 	__shared__ unsigned int s_next;
-	const WalkStack stack = { (int*)s_dyn + threadIdx.x, spill + blockIdx.x * JP_BLOCK + threadIdx.x, kMode == 4 ? stack_cap - 1 : stack_cap, gridDim.x * JP_BLOCK };   // Walker<4>: the last LDS word is its dump slot
+	const WalkStack stack = { (int*)s_dyn + threadIdx.x, spill + blockIdx.x * JP_BLOCK + threadIdx.x, (kMode == 4 || kMode == 6) ? stack_cap - 1 : stack_cap, gridDim.x * JP_BLOCK };   // Walker<4> / <6>: the last LDS word is the dump slot
 	unsigned int* s_occ = (unsigned int*)s_dyn + stack_cap * JP_BLOCK;   // bit r set: ray r is occluded
 	const unsigned int b = blockIdx.x, E = q.blk_sh[b], rbase = b * q.R;
 	const unsigned int NP = (unsigned int)rc.n_planes, total = E * NP;
-	for (unsigned int i = threadIdx.x; i < (total + 31) / 32; i += JP_BLOCK) s_occ[i] = 0;
+	unsigned int* s_uns = s_occ + ((size_t)q.R * NP + 31) / 32;          // Walker<6>: bit r set: ray r could not be certified
+	for (unsigned int i = threadIdx.x; i < (total + 31) / 32; i += JP_BLOCK) { s_occ[i] = 0; if (kMode == 6) s_uns[i] = 0; }
 	if (threadIdx.x == 0) s_next = 0;
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
@@ -885,7 +912,12 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shadow_persist(SceneView sc, Queue
 		const int nidle = __popcll(idle);
 		if (nidle == 64 || (pool && nidle >= kRefill))
 		{
-			if (w.done && rid != 0xffffffffu) { if (w.hit >= 0) atomicOr(&s_occ[rid >> 5], 1u << (rid & 31u)); rid = 0xffffffffu; }
+			if (w.done && rid != 0xffffffffu)
+			{
+				if (w.hit >= 0) atomicOr(&s_occ[rid >> 5], 1u << (rid & 31u));
+				if constexpr (kMode == 6) { if (w.hit < 0 && w.unsure) atomicOr(&s_uns[rid >> 5], 1u << (rid & 31u)); }
+				rid = 0xffffffffu;
+			}
 			if (!pool) break;
 			const int first = __ffsll((long long)idle) - 1;
 			unsigned int start = 0;
@@ -917,6 +949,23 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shadow_persist(SceneView sc, Queue
 		}
 	}
 	__syncthreads();
+	if constexpr (kMode == 6)
+	{   // the rays without a certificate, FBVH_Node::Intersect's own walk
+		for (unsigned int i = threadIdx.x; i < (total + 31) / 32; i += JP_BLOCK)
+		{
+			unsigned int bits = s_uns[i];
+			while (bits)
+			{
+				const unsigned int r = i * 32u + (unsigned int)(__ffs((int)bits) - 1); bits &= bits - 1u;
+				const unsigned int k = r / E, e = r - k * E;
+				const float4 so = q.sh_o[rbase + e], sd = q.sh_d[(size_t)k * q.cap + rbase + e];
+				float tm = sd.w;
+				if (walk_ray<5, true>(sc, xyz(so), xyz(sd), 0.001f, tm, stack) >= 0) atomicOr(&s_occ[r >> 5], 1u << (r & 31u));
+				if (cnt) atomicAdd(&cnt->cert_fallback, 1ull);
+			}
+		}
+		__syncthreads();
+	}
 	// ---- the entries' sums, in light order ----
 	unsigned int rays = 0, occ = 0;
 	for (unsigned int e = threadIdx.x; e < E; e += JP_BLOCK)
@@ -1309,6 +1358,7 @@ struct JpContext
 	// stream of the lane (own spill area) and run beside the next extend launch; the next k_shade waits for both
 	bool dual = false; hipStream_t stream2 = nullptr; hipEvent_t ev_shade = nullptr, ev_shadow = nullptr; int* d_spill2 = nullptr; size_t spill2_words = 0;
 	size_t trav_lds_pad = 0;                                                           // experiment: extra dynamic LDS of the refill kernels = fewer of their workgroups per CU (room for another lane's k_shade)
+	void* d_refbox = nullptr; bool cert = false;                                       // reference semantics, certified walk (Walker<6>): leaf boxes per primitive
 	bool use_q4 = false, q4_shadow = false;                                            // closest-hit (and, as an experiment, shadow) rays walk the 4-wide quantised tree (Walker<4>)
 	bool vote = false; int persist = 0;                                             // lane refill in the closest-hit traversal of large scenes (k_extend_persist): refill threshold, 0 = off
 	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr, *d_shade_tab = nullptr;
@@ -1350,7 +1400,7 @@ struct JpContext
 
 static void free_scene(JpContext* c)
 {
-	void** ps[] = { &c->d_flat, &c->d_cut, &c->d_wide, &c->d_q4, &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights, &c->d_shade_tab };
+	void** ps[] = { &c->d_flat, &c->d_cut, &c->d_wide, &c->d_q4, &c->d_refbox, &c->d_nodes, &c->d_prims, &c->d_meta, &c->d_mats, &c->d_mat_type, &c->d_lights, &c->d_shade_tab };
 	for (void** p : ps) { if (*p) hipFree(*p); *p = nullptr; }
 	c->have_scene = false;
 }
@@ -1572,6 +1622,63 @@ inline HV3 hcross(HV3 a, HV3 v) { HV3 r = { a.y * v.z - a.z * v.y, a.z * v.x - a
 inline float hlen(HV3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
 inline HV3 hld(const float* p) { HV3 r = { p[0], p[1], p[2] }; return r; }
 
+// Binned-SAH binary tree over ITEM boxes with one item per leaf (certified walk: the items are the leaves of the caller's tree).
+// left[n] >= 0: interior (left[n], right[n]); left[n] < 0: leaf holding item -left[n] - 1.  bounds: 6 floats per node.  Root = node 0.
+struct ItemTree { std::vector<int> left, right; std::vector<float> bounds; int height = 0; };
+int item_tree_build(const std::vector<float>& ib, std::vector<int>& idx, int start, int end, ItemTree& t, int depth)
+{
+	const int node = (int)t.left.size(); t.left.push_back(0); t.right.push_back(0); t.bounds.resize(t.bounds.size() + 6);
+	t.height = std::max(t.height, depth);
+	float nb[6] = { 1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f }, cb[6] = { 1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f };
+	for (int i = start; i < end; i++)
+	{
+		const float* b = &ib[6 * (size_t)idx[i]];
+		for (int a = 0; a < 3; a++) { nb[a] = std::min(nb[a], b[a]); nb[3 + a] = std::max(nb[3 + a], b[3 + a]); const float c = 0.5f * (b[a] + b[3 + a]); cb[a] = std::min(cb[a], c); cb[3 + a] = std::max(cb[3 + a], c); }
+	}
+	std::memcpy(&t.bounds[6 * (size_t)node], nb, sizeof(nb));
+	if (end - start == 1) { t.left[node] = -idx[start] - 1; return node; }
+	auto area = [](const float* b) { const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2]; return (dx < 0 || dy < 0 || dz < 0) ? 0.f : dx * dy + dy * dz + dz * dx; };
+	const int NB = 16; float bestCost = 3.0e38f; int bestAxis = -1, bestBin = -1;
+	for (int a = 0; a < 3; a++)
+	{
+		const float lo = cb[a], hi = cb[3 + a]; if (!(hi > lo)) continue;
+		float bins[NB][6]; int cnt[NB];
+		for (int k = 0; k < NB; k++) { for (int j = 0; j < 3; j++) { bins[k][j] = 1e30f; bins[k][3 + j] = -1e30f; } cnt[k] = 0; }
+		const float scale = NB / (hi - lo);
+		for (int i = start; i < end; i++)
+		{
+			const float* b = &ib[6 * (size_t)idx[i]];
+			int k = (int)((0.5f * (b[a] + b[3 + a]) - lo) * scale); k = std::max(0, std::min(NB - 1, k));
+			for (int j = 0; j < 3; j++) { bins[k][j] = std::min(bins[k][j], b[j]); bins[k][3 + j] = std::max(bins[k][3 + j], b[3 + j]); } cnt[k]++;
+		}
+		float rightArea[NB]; int rightCnt[NB]; float acc[6] = { 1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f }; int c = 0;
+		for (int k = NB - 1; k > 0; k--) { for (int j = 0; j < 3; j++) { acc[j] = std::min(acc[j], bins[k][j]); acc[3 + j] = std::max(acc[3 + j], bins[k][3 + j]); } c += cnt[k]; rightArea[k] = area(acc); rightCnt[k] = c; }
+		for (int j = 0; j < 3; j++) { acc[j] = 1e30f; acc[3 + j] = -1e30f; } c = 0;
+		for (int k = 0; k < NB - 1; k++)
+		{
+			for (int j = 0; j < 3; j++) { acc[j] = std::min(acc[j], bins[k][j]); acc[3 + j] = std::max(acc[3 + j], bins[k][3 + j]); } c += cnt[k];
+			if (c == 0 || rightCnt[k + 1] == 0) continue;
+			const float cost = area(acc) * c + rightArea[k + 1] * rightCnt[k + 1];
+			if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = k; }
+		}
+	}
+	int mid = -1;
+	if (bestAxis >= 0)
+	{
+		const int a = bestAxis; const float lo = cb[a], scale = NB / (cb[3 + a] - cb[a]);
+		int* m = std::partition(idx.data() + start, idx.data() + end, [&](int i) { const float* b = &ib[6 * (size_t)i]; int k = (int)((0.5f * (b[a] + b[3 + a]) - lo) * scale); k = std::max(0, std::min(NB - 1, k)); return k <= bestBin; });
+		mid = (int)(m - idx.data());
+	}
+	if (mid <= start || mid >= end)
+	{   // coinciding centroids: split the range in the middle
+		mid = start + (end - start) / 2;
+	}
+	const int l = item_tree_build(ib, idx, start, mid, t, depth + 1);
+	const int r = item_tree_build(ib, idx, mid, end, t, depth + 1);
+	t.left[node] = l; t.right[node] = r;
+	return node;
+}
+
 int bvh_height(const JpScene* s, int node, int depth, int limit, bool& bad, std::vector<char>& seen)
 {
 	if (node < 0 || node >= s->n_bvh_nodes || seen[node] || depth > limit) { bad = true; return 0; }
@@ -1591,7 +1698,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	if (s->n_triangles < 0 || s->n_rectangles < 0 || s->n_spheres < 0 || s->n_disks < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_bvh_nodes < 0 || s->n_bvh_prim_indices < 0)
 		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: negative count");
 	const bool device_build = s->n_bvh_nodes == 0;              // no hierarchy handed over: build it on the device (jp_lbvh.h)
-	const bool ref_sem = !device_build && s->bvh_reference_semantics == 1;   // walk the caller's tree with the reference's semantics (traverse_ref)
+	const bool ref_sem = !device_build && (s->bvh_reference_semantics == 1 || s->bvh_reference_semantics == 2);   // walk the caller's tree with the reference's semantics (traverse_ref)
 	if (!s->prim_shape_type || !s->prim_shape_index || !s->prim_material || !s->prim_light || (!device_build && (!s->bvh_bounds || !s->bvh_left || !s->bvh_right || !s->bvh_prim_index)))
 		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: null array");
 	if ((s->n_triangles && (!s->tri_p0 || !s->tri_p1 || !s->tri_p2 || !s->tri_n)) || (s->n_rectangles && (!s->rect_p0 || !s->rect_p1 || !s->rect_p2 || !s->rect_p3 || !s->rect_n))
@@ -1812,6 +1919,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	std::vector<int> order;
 	if (!device_build && !ref_sem) { std::vector<int> st; st.push_back(0); while (!st.empty()) { int n = st.back(); st.pop_back(); if (s->bvh_left[n] < 0) continue; hostToDevNode[n] = (int)order.size(); order.push_back(n); st.push_back(s->bvh_right[n]); st.push_back(s->bvh_left[n]); } }
 	const float kEmpty[6] = { 1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f };
+	std::vector<int> cert_item_first, cert_item_cnt; std::vector<float> cert_item_box;     // reference semantics: the leaves of the caller's tree (device primitive range, exact box)
 	if (device_build) {}
 	else if (ref_sem)
 	{   // the caller's nodes under their own indices, unpadded boxes; primitives in the leaves' visiting order (left before right)
@@ -1828,6 +1936,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 				const int dfirst = (int)meta.size();
 				for (int k = 0; k < cnt; k++) emit_prim(s->bvh_prim_index[first + k]);
 				l = -dfirst - 1;
+				cert_item_first.push_back(dfirst); cert_item_cnt.push_back(cnt); cert_item_box.insert(cert_item_box.end(), b, b + 6);
 			}
 			else { st.push_back(r); st.push_back(l); }
 			float fl, fr; std::memcpy(&fl, &l, 4); std::memcpy(&fr, &r, 4);
@@ -1860,31 +1969,29 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	// ---- large scenes: the binary tree collapsed into 4-wide nodes with quantised child boxes for the closest-hit rays (Walker<4>) ----
 	// From binary node b: its two children, then the interior child with the largest box is opened again while fewer than four
 	// slots are taken.  Leaves keep the binary tree's encoding and primitive records.  JETPBRT_Q4=0: closest hits walk the binary tree.
-	std::vector<uint32_t> q4; int q4_height = 0;
-	bool use_q4 = !device_build && !ref_sem && s->n_primitives > 1024 && s->bvh_left[0] >= 0 && !order.empty();
-	if (const char* e = getenv("JETPBRT_Q4")) use_q4 = use_q4 && atoi(e) != 0;
-	if (use_q4)
+	// (one collapse for two sources: the caller's tree as it is, and -- reference semantics, certified walk -- the tree built below over the caller's leaves)
+	auto collapse_q4 = [&](size_t n_nodes, auto isInner, auto leftOf, auto rightOf, auto boxOf, auto leafRefOf, std::vector<uint32_t>& q4, int& q4_height) -> bool
 	{
 		struct Item { int bnode; uint32_t idx; int depth; };
 		auto area = [](const float* b) { float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2]; return dx * dy + dy * dz + dz * dx; };
-		std::vector<Item> queue; queue.reserve((size_t)s->n_bvh_nodes / 2 + 16); queue.push_back({ 0, 0u, 1 });
-		q4.reserve(((size_t)s->n_bvh_nodes / 2 + 16) * 16); q4.assign(16, 0u);
+		std::vector<Item> queue; queue.reserve(n_nodes / 2 + 16); queue.push_back({ 0, 0u, 1 });
+		q4.clear(); q4_height = 0; q4.reserve((n_nodes / 2 + 16) * 16); q4.assign(16, 0u);
 		bool ok = true;
 		for (size_t qi = 0; qi < queue.size() && ok; qi++)
 		{
 			const Item it = queue[qi];
 			q4_height = std::max(q4_height, it.depth);
 			int ch[4]; float cb[4][6]; int nc = 0;
-			ch[nc] = s->bvh_left[it.bnode]; pad_box(ch[nc], cb[nc]); nc++;
-			ch[nc] = s->bvh_right[it.bnode]; pad_box(ch[nc], cb[nc]); nc++;
+			ch[nc] = leftOf(it.bnode); boxOf(ch[nc], cb[nc]); nc++;
+			ch[nc] = rightOf(it.bnode); boxOf(ch[nc], cb[nc]); nc++;
 			while (nc < 4)
 			{
 				int best = -1; float bestA = -1.f;
-				for (int k = 0; k < nc; k++) if (s->bvh_left[ch[k]] >= 0 && area(cb[k]) > bestA) { bestA = area(cb[k]); best = k; }
+				for (int k = 0; k < nc; k++) if (isInner(ch[k]) && area(cb[k]) > bestA) { bestA = area(cb[k]); best = k; }
 				if (best < 0) break;
 				const int n = ch[best];
-				ch[best] = s->bvh_left[n]; pad_box(ch[best], cb[best]);
-				ch[nc] = s->bvh_right[n]; pad_box(ch[nc], cb[nc]); nc++;
+				ch[best] = leftOf(n); boxOf(ch[best], cb[best]);
+				ch[nc] = rightOf(n); boxOf(ch[nc], cb[nc]); nc++;
 			}
 			float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
 			for (int k = 0; k < nc; k++) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], cb[k][a]); hi[a] = std::max(hi[a], cb[k][3 + a]); }
@@ -1896,7 +2003,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 				eb[a] = e + 127; sc3[a] = std::ldexp(1.0f, e);
 			}
 			// Walker<4> evaluates a slab distance as q * (2^e / d) + (p - o) / d: its rounding error grows with the NODE's extent, so every
-			// child box gets 1e-6 of the node's extent on top of the relative padding of pad_box before it is quantised outward
+			// child box gets 1e-6 of the node's extent on top of the relative padding of the box source before it is quantised outward
 			for (int k = 0; k < nc; k++) for (int a = 0; a < 3; a++) { const float ex = 1e-6f * (hi[a] - lo[a]); cb[k][a] -= ex; cb[k][3 + a] += ex; }
 			for (int a = 0; a < 3; a++) { const float ex = 1e-6f * (hi[a] - lo[a]); lo[a] -= ex; hi[a] += ex; }
 			for (int a = 0; a < 3; a++)
@@ -1912,8 +2019,8 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 				valid |= 1u << k;
 				const int n = ch[k];
 				int r;
-				if (s->bvh_left[n] >= 0) { r = (int)(q4.size() / 16); queue.push_back({ n, (uint32_t)r, it.depth + 1 }); q4.resize(q4.size() + 16, 0u); }
-				else r = emit_leaf(n);
+				if (isInner(n)) { r = (int)(q4.size() / 16); queue.push_back({ n, (uint32_t)r, it.depth + 1 }); q4.resize(q4.size() + 16, 0u); }
+				else r = leafRefOf(n);
 				std::memcpy(&refs[k], &r, 4);
 				for (int a = 0; a < 3; a++)
 				{
@@ -1934,7 +2041,60 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 			w[8] = pack4(ql[0]); w[9] = pack4(ql[1]); w[10] = pack4(ql[2]); w[11] = pack4(qh[0]);
 			w[12] = pack4(qh[1]); w[13] = pack4(qh[2]); w[14] = 0; w[15] = 0;
 		}
+		return ok;
+	};
+	std::vector<uint32_t> q4; int q4_height = 0;
+	bool use_q4 = !device_build && !ref_sem && s->n_primitives > 1024 && s->bvh_left[0] >= 0 && !order.empty();
+	if (const char* e = getenv("JETPBRT_Q4")) use_q4 = use_q4 && atoi(e) != 0;
+	if (use_q4)
+	{
+		const bool ok = collapse_q4((size_t)s->n_bvh_nodes, [&](int n) { return s->bvh_left[n] >= 0; }, [&](int n) { return s->bvh_left[n]; }, [&](int n) { return s->bvh_right[n]; },
+		                            [&](int n, float* bb) { pad_box(n, bb); }, [&](int n) { return emit_leaf(n); }, q4, q4_height);
 		if (!ok || (int)meta.size() != s->n_primitives) { use_q4 = false; q4.clear(); }
+	}
+
+	// ---- reference semantics on large scenes: the certified walk (Walker<6>, jp_device.h) ----
+	// A binned-SAH tree over the LEAVES of the caller's tree (their exact boxes, padded like every box of the ordered walks), collapsed to 4-wide
+	// nodes; a leaf of it is one leaf of the caller's tree (same primitive range, same order).  Per primitive the exact box of its leaf
+	// (the certificate is FBounds3::Intersect on that box).  The caller's nodes stay on the device for the rays that get no certificate.
+	bool want_cert = s->bvh_reference_semantics == 2;
+	if (const char* e = getenv("JETPBRT_CERTIFIED")) want_cert = atoi(e) != 0;                // (experiments: either way round)
+	bool use_cert = want_cert && ref_sem && s->n_primitives > 1024 && cert_item_first.size() >= 64;
+	std::vector<float4> refbox; float cert_pad = 0.f;
+	if (use_cert)
+	{
+		const int ni = (int)cert_item_first.size();
+		ItemTree it; std::vector<int> idx(ni); for (int i = 0; i < ni; i++) idx[i] = i;
+		it.left.reserve(2 * (size_t)ni); it.right.reserve(2 * (size_t)ni); it.bounds.reserve(12 * (size_t)ni);
+		item_tree_build(cert_item_box, idx, 0, ni, it, 1);
+		auto box_of = [&](int n, float* bb) {
+			for (int a = 0; a < 3; a++)
+			{
+				const float lo = it.bounds[6 * (size_t)n + a], hi = it.bounds[6 * (size_t)n + 3 + a];
+				const float m = std::max(std::fabs(lo), std::fabs(hi)), e = m * 1e-6f + 1e-6f + extra_pad;
+				bb[a] = lo - e; bb[3 + a] = hi + e;
+			}
+		};
+		bool ok = it.left[0] >= 0 && it.height + 2 <= 48;
+		for (int i = 0; i < ni && ok; i++) if (cert_item_cnt[i] < 1 || cert_item_cnt[i] > 16) ok = false;
+		if (ok) ok = collapse_q4(it.left.size(), [&](int n) { return it.left[n] >= 0; }, [&](int n) { return it.left[n]; }, [&](int n) { return it.right[n]; }, box_of,
+		                         [&](int n) { const int item = -it.left[n] - 1; return -(((cert_item_first[item] << 4) | (cert_item_cnt[item] - 1)) + 1); }, q4, q4_height);
+		if (!ok) { use_cert = false; q4.clear(); }
+		else
+		{
+			refbox.resize((size_t)2 * s->n_primitives);
+			double diag = 0;
+			for (int i = 0; i < ni; i++)
+			{
+				const float* b = &cert_item_box[6 * (size_t)i];
+				for (int k = 0; k < cert_item_cnt[i]; k++) { const size_t p = (size_t)cert_item_first[i] + k; refbox[2 * p] = make_float4(b[0], b[1], b[2], 0.f); refbox[2 * p + 1] = make_float4(b[3], b[4], b[5], 0.f); }
+				diag += std::sqrt((double)(b[3] - b[0]) * (b[3] - b[0]) + (double)(b[4] - b[1]) * (b[4] - b[1]) + (double)(b[5] - b[2]) * (b[5] - b[2]));
+			}
+			// distance-cull slack: a hit in the fp32 acceptance fringe of FTriangle::Intersect lies up to ~ eps * D^2 / edge beside its triangle (D: distance
+			// from the ray origin), so up to a few times that in front of its leaf's box: tmax + K * eps / (mean leaf diagonal) * tmax^2
+			float K = 1024.f; if (const char* e = getenv("JETPBRT_CERT_SLACK")) K = std::max(0.f, (float)atof(e));
+			cert_pad = (float)(K * 1.1920929e-7 / std::max(1e-20, diag / ni));
+		}
 	}
 
 	// ---- no hierarchy handed over: records go up in creation order and the tree is built on the device (jp_lbvh.h) ----
@@ -2120,7 +2280,8 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		HIP_TRY(up(&c->d_shade_tab, tabv.data(), tabv.size() * sizeof(float4)));
 	}
 	if (use_wide && !dev_wide) HIP_TRY(up(&c->d_wide, wide.data(), wide.size() * sizeof(uint32_t)));
-	if (use_q4 && !dev_q4) HIP_TRY(up(&c->d_q4, q4.data(), q4.size() * sizeof(uint32_t)));
+	if ((use_q4 && !dev_q4) || use_cert) HIP_TRY(up(&c->d_q4, q4.data(), q4.size() * sizeof(uint32_t)));
+	if (use_cert) HIP_TRY(up(&c->d_refbox, refbox.data(), refbox.size() * sizeof(float4)));
 	if (!flat.empty()) HIP_TRY(up(&c->d_flat, flat.data(), flat.size() * sizeof(float4)));
 	if (!cut.empty()) HIP_TRY(up(&c->d_cut, cut.data(), cut.size() * sizeof(float4)));
 
@@ -2135,12 +2296,13 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.cut = (const float4*)c->d_cut; v.n_cut = (int)(cut.size() / 2);
 	v.wide = (const uint4*)c->d_wide; v.n_wide = dev_wide ? dev_n_wide : (int)(wide.size() / 20);
 	v.q4 = (const uint4*)c->d_q4; v.n_q4 = dev_q4 ? dev_n_q4 : (int)(q4.size() / 16);
+	v.refbox = (const float4*)c->d_refbox; v.cert_pad = cert_pad; c->cert = use_cert;
 	c->dual = false; if (const char* e = getenv("JETPBRT_DUAL")) c->dual = atoi(e) != 0;
 	c->trav_lds_pad = 0; if (const char* e = getenv("JETPBRT_TRAV_LDS_PAD")) { const long v = atol(e); if (v > 0 && v <= 48 * 1024) c->trav_lds_pad = (size_t)v & ~(size_t)15; }
 	c->use_q4 = use_q4; c->q4_shadow = use_q4;                       // shadow rays too (measured against the 8-wide tree: k_shadow 53.8 -> 52.7 ms per 512 spp, frame +4 %)
 	if (const char* e = getenv("JETPBRT_Q4_SHADOW")) c->q4_shadow = use_q4 && atoi(e) != 0;
 	c->stack_depth = std::max(2, height + 2);
-	if (use_q4) c->stack_depth = std::max(c->stack_depth, 3 * q4_height + 2);      // a 4-wide node pushes up to three children
+	if (use_q4 || use_cert) c->stack_depth = std::max(c->stack_depth, 3 * q4_height + 2);      // a 4-wide node pushes up to three children
 	size_t scene_bytes = (n4nodes + n4prims) / 4 * 5 * sizeof(float4);   // 80-byte LDS record stride
 	size_t prim_bytes = n4prims / 4 * 5 * sizeof(float4);
 	size_t stack_bytes = (size_t)c->stack_depth * JP_BLOCK * sizeof(int);
@@ -2182,7 +2344,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		// each iteration the lanes of a wave vote on the kind of step it runs (node / leaf); measured on the 280k-triangle scene: k_extend
 		// 28.3 -> 21.9 ms, k_shadow 18.9 -> 16.5 ms per 128 spp.  The reference-tree walk (one node per step, leaf objects as their own
 		// steps) is faster without it: 310 vs 286 Msamples/s.
-		c->vote = c->trav_mode != 5; if (const char* e = getenv("JETPBRT_VOTE")) c->vote = atoi(e) != 0;
+		c->vote = c->trav_mode != 5 || c->cert; if (const char* e = getenv("JETPBRT_VOTE")) c->vote = atoi(e) != 0;
 		c->ray_sort = false;                                        // opt-in: JETPBRT_RAY_SORT=1 (tiny scenes: by primitive-test count; others: by cut boxes entered)
 		if (const char* e = getenv("JETPBRT_RAY_SORT")) c->ray_sort = atoi(e) != 0 && (c->trav_mode == 2 || ((c->trav_mode == 0 || c->trav_mode == 3) && !cut.empty()));
 		c->shade_sort = nk > 1;
@@ -2353,7 +2515,8 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 					{
 						const int ecap = std::min(c->stack_depth, c->stack_lds_words); const size_t elds = (size_t)ecap * JP_BLOCK * sizeof(int) + c->trav_lds_pad;
 						#define JP_LAUNCH_EP(M, R) do { if (c->vote) hipLaunchKernelGGL((k_extend_persist<M, R, true>), dim3(grid), dim3(JP_BLOCK), elds, c->stream, c->sv, c->q, cur, ecap, c->d_spill, c->d_cnt); else hipLaunchKernelGGL((k_extend_persist<M, R, false>), dim3(grid), dim3(JP_BLOCK), elds, c->stream, c->sv, c->q, cur, ecap, c->d_spill, c->d_cnt); } while (0)
-						if (c->trav_mode == 5) { if (c->persist >= 32) JP_LAUNCH_EP(5, 32); else if (c->persist >= 16) JP_LAUNCH_EP(5, 16); else JP_LAUNCH_EP(5, 8); }
+						if (c->trav_mode == 5 && c->cert) { if (c->persist >= 32) JP_LAUNCH_EP(6, 32); else if (c->persist >= 16) JP_LAUNCH_EP(6, 16); else JP_LAUNCH_EP(6, 8); }
+						else if (c->trav_mode == 5) { if (c->persist >= 32) JP_LAUNCH_EP(5, 32); else if (c->persist >= 16) JP_LAUNCH_EP(5, 16); else JP_LAUNCH_EP(5, 8); }
 						else if (c->use_q4) { if (c->persist >= 32) JP_LAUNCH_EP(4, 32); else if (c->persist >= 16) JP_LAUNCH_EP(4, 16); else JP_LAUNCH_EP(4, 8); }
 						else { if (c->persist >= 32) JP_LAUNCH_EP(0, 32); else if (c->persist >= 16) JP_LAUNCH_EP(0, 16); else JP_LAUNCH_EP(0, 8); }
 						#undef JP_LAUNCH_EP
@@ -2388,11 +2551,12 @@ int render_one(JpContext* c, const JpRenderParams* rp, float* film_dev, bool syn
 					Stamper t(c, CLS_SHADOW, sstream);
 					const size_t slds = c->q4_shadow ? (size_t)c->stack_depth * JP_BLOCK * sizeof(int) : (c->trav_mode == 3 ? c->lds_bytes_shadow : lds);
 					const int scap = std::min((int)(slds / (JP_BLOCK * sizeof(int))), c->stack_lds_words);     // stack words per thread kept in LDS
-					const size_t plds = (size_t)scap * JP_BLOCK * sizeof(int) + (((size_t)c->q.R * c->n_planes + 31) / 32) * 4 + c->trav_lds_pad;
+					const size_t plds = (size_t)scap * JP_BLOCK * sizeof(int) + (((size_t)c->q.R * c->n_planes + 31) / 32) * 4 * (c->cert ? 2 : 1) + c->trav_lds_pad;   // (certified walk: a second bitmap, the rays without a certificate)
 					if (c->persist && (c->trav_mode == 0 || c->trav_mode == 3 || c->trav_mode == 5) && plds <= 64 * 1024)
 					{
 						#define JP_LAUNCH_SP(M, R) do { if (c->vote) hipLaunchKernelGGL((k_shadow_persist<M, R, true>), dim3(grid), dim3(JP_BLOCK), plds, sstream, c->sv, c->q, rc, scap, sspill, c->d_cnt); else hipLaunchKernelGGL((k_shadow_persist<M, R, false>), dim3(grid), dim3(JP_BLOCK), plds, sstream, c->sv, c->q, rc, scap, sspill, c->d_cnt); } while (0)
-						if (c->trav_mode == 5) { if (c->persist >= 32) JP_LAUNCH_SP(5, 32); else if (c->persist >= 16) JP_LAUNCH_SP(5, 16); else JP_LAUNCH_SP(5, 8); }
+						if (c->trav_mode == 5 && c->cert) { if (c->persist >= 32) JP_LAUNCH_SP(6, 32); else if (c->persist >= 16) JP_LAUNCH_SP(6, 16); else JP_LAUNCH_SP(6, 8); }
+						else if (c->trav_mode == 5) { if (c->persist >= 32) JP_LAUNCH_SP(5, 32); else if (c->persist >= 16) JP_LAUNCH_SP(5, 16); else JP_LAUNCH_SP(5, 8); }
 						else if (c->q4_shadow) { if (c->persist >= 32) JP_LAUNCH_SP(4, 32); else if (c->persist >= 16) JP_LAUNCH_SP(4, 16); else JP_LAUNCH_SP(4, 8); }
 						else if (c->trav_mode == 3) { if (c->persist >= 32) JP_LAUNCH_SP(3, 32); else if (c->persist >= 16) JP_LAUNCH_SP(3, 16); else JP_LAUNCH_SP(3, 8); }
 						else { if (c->persist >= 32) JP_LAUNCH_SP(0, 32); else if (c->persist >= 16) JP_LAUNCH_SP(0, 16); else JP_LAUNCH_SP(0, 8); }
@@ -2458,7 +2622,7 @@ void sync_lane_scene(JpContext* c, JpContext* l)
 	l->have_scene = c->have_scene; l->sv = c->sv; l->stack_depth = c->stack_depth; l->scene_in_lds = c->scene_in_lds; l->shade_prims_in_lds = c->shade_prims_in_lds;
 	l->lds_bytes = c->lds_bytes; l->lds_bytes_shadow = c->lds_bytes_shadow; l->trav_mode = c->trav_mode; l->n_planes = c->n_planes;
 	l->stack_lds_words = c->stack_lds_words;
-	l->use_q4 = c->use_q4; l->q4_shadow = c->q4_shadow; l->trav_lds_pad = c->trav_lds_pad; l->dual = c->dual;
+	l->use_q4 = c->use_q4; l->q4_shadow = c->q4_shadow; l->trav_lds_pad = c->trav_lds_pad; l->dual = c->dual; l->cert = c->cert;
 	l->ray_sort = c->ray_sort; l->persist = c->persist; l->vote = c->vote; l->shade_sort = c->shade_sort; l->class_mask = c->class_mask;
 	l->has_null_material = c->has_null_material; l->tables_in_lds = c->tables_in_lds; l->stage_nee = c->stage_nee; l->shade_lds_bytes = c->shade_lds_bytes;
 	l->profiling = c->profiling;
@@ -2694,7 +2858,7 @@ int finish_one(JpContext* c, JpCounters& o)
 {
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	DevCounters h; HIP_TRY(hipMemcpy(&h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost));
-	o.closest_rays += h.closest; o.closest_hits += h.closest_hit; o.shadow_rays += h.shadow; o.shadow_occluded += h.shadow_occ;
+	o.closest_rays += h.closest; o.closest_hits += h.closest_hit; o.shadow_rays += h.shadow; o.shadow_occluded += h.shadow_occ; o.certified_fallback_rays += h.cert_fallback;
 	for (const JpContext::Stamp& s : c->stamps)
 	{
 		float t = 0.f; if (hipEventElapsedTime(&t, c->evpool[s.a], c->evpool[s.b]) != hipSuccess) continue;
@@ -2778,6 +2942,7 @@ int jp_get_build_info(JpContext* c, JpBuildInfo* out)
 	out->device_build_ms = c->build_ms; out->libm_sincosf = c->sincosf_mode; out->lanes_last_render = c->last_lanes;
 	out->fused_last_render = c->last_fused; out->fused_region = c->last_region; out->fused_workgroups = c->last_wgs;
 	out->q4_nodes = c->use_q4 ? c->sv.n_q4 : 0; out->libm_xbsdf = c->libm_mode;
+	out->certified_walk = c->cert ? 1 : 0; out->certified_nodes = c->cert ? c->sv.n_q4 : 0;
 	return JP_OK;
 }
 
@@ -2835,6 +3000,7 @@ int jp_trace(JpContext* c, int32_t n, const float* origin, const float* dir, con
 		hipMemcpyAsync(d_t0, tmin, (size_t)n * 4, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(d_t1, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
 		int grid = std::min(c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK);
 		if (c->trav_mode == 3 && getenv("JETPBRT_TRACE_WIDE")) hipLaunchKernelGGL(k_trace<3>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes_shadow, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
+		else if (c->trav_mode == 5 && c->cert && !getenv("JETPBRT_TRACE_VERBATIM")) hipLaunchKernelGGL(k_trace<6>, dim3(grid), dim3(JP_BLOCK), (size_t)c->stack_depth * JP_BLOCK * sizeof(int), c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		else if (c->trav_mode == 5) hipLaunchKernelGGL(k_trace<5>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		else if (c->use_q4 && !getenv("JETPBRT_TRACE_BINARY")) hipLaunchKernelGGL(k_trace<4>, dim3(grid), dim3(JP_BLOCK), (size_t)c->stack_depth * JP_BLOCK * sizeof(int), c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		else if (c->trav_mode == 2) hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);

@@ -73,7 +73,7 @@ void jp_host_scene_sphere(void* h, const float* center, float radius, int mat, c
 void jp_host_scene_disk(void* h, const float* pos, const float* normal, float radius, int mat, const float* radiance)
 { HostScene* hs = (HostScene*)h; attach(hs, hs->scene->CreateShape<FDisk>(V3(pos), V3(normal), radius), mat, radiance); }
 
-void jp_host_scene_set_reference_tree(void* h, int on) { ((HostScene*)h)->scene->referenceTree = on != 0; }
+void jp_host_scene_set_reference_tree(void* h, int on) { ((HostScene*)h)->scene->referenceTree = on != 0; ((HostScene*)h)->scene->certifiedWalk = on == 2; }   // 1: verbatim walk, 2: certified walk
 void jp_host_scene_set_device_build(void* h, int on) { ((HostScene*)h)->scene->deviceBuild = on != 0; ((HostScene*)h)->scene->hostBuild = on == 0; }   // explicit either way
 void jp_host_scene_preprocess(void* h) { HostScene* hs = (HostScene*)h; hs->scene->Preprocess(); hs->flattened = false; }
 int  jp_host_num_primitives(void* h) { return (int)((HostScene*)h)->scene->primitives.size(); }

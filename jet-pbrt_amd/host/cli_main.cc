@@ -1,5 +1,5 @@
 // jet-pbrt_amd/host/cli_main.cc -- the reference's command line (main.cc:113-163) on the GPU integrator:
-//     jetpbrt sceneid spp [width height] [--assets DIR] [--out NAME] [--format bmp|ppm|hdr] [--device-bvh | --reference-tree] [--integrator path|recursive|whitted|debug]
+//     jetpbrt sceneid spp [width height] [--assets DIR] [--out NAME] [--format bmp|ppm|hdr] [--device-bvh | --reference-tree | --reference-tree=certified] [--integrator path|recursive|whitted|debug]
 // sceneid 0 = Cornell box, 1 = bunny scene; spp defaults to 50, the film to 1024 x 1024, the output to
 // <scene name>_<spp>.bmp, as in the reference.  The scene scripts are the calls of main.cc:13-111; the meshes are
 // read from DIR/cornellbox/{light,floor,shortbox,tallbox,left,right}.obj and DIR/bunny/bunny.obj (the reference
@@ -81,6 +81,7 @@ int main(int argc, char* argv[])
 		else if (!strcmp(argv[i], "--device-bvh")) setenv("JETPBRT_DEVICE_BVH", "1", 1);   // FScene::deviceBuild for the scenes created below
 		else if (!strcmp(argv[i], "--integrator") && i + 1 < argc) integratorName = argv[++i];
 		else if (!strcmp(argv[i], "--reference-tree")) setenv("JETPBRT_REFERENCE_TREE", "1", 1);   // FScene::referenceTree: the reference's own BVH and traversal semantics
+		else if (!strcmp(argv[i], "--reference-tree=certified")) setenv("JETPBRT_REFERENCE_TREE", "2", 1);   // ... with the certified walk (FScene::certifiedWalk)
 		else pos.push_back(argv[i]);
 	}
 	if (pos.empty()) return 0;                                    // main.cc:122-125

@@ -226,7 +226,7 @@ void FScene::Preprocess()                                                // scen
 	for (auto& p : primitives) bound.Expand(p->shape->WorldBounds());     // scene.cc:35-45
 	worldBound = bound;
 	for (auto& l : lights) l->Preprocess(*this);
-	if (const char* e = getenv("JETPBRT_REFERENCE_TREE")) if (atoi(e) == 1) referenceTree = true;
+	if (const char* e = getenv("JETPBRT_REFERENCE_TREE")) { if (atoi(e) == 1 || atoi(e) == 2) referenceTree = true; if (atoi(e) == 2) certifiedWalk = true; }
 	if (referenceTree)
 	{
 		std::vector<FBounds3> wb; wb.reserve(primitives.size());
@@ -330,7 +330,7 @@ bool FlattenScene(const FScene& scene, FlatScene& out, std::string* error)
 	v.n_materials = (int)out.mat_type.size(); v.mat_type = out.mat_type.data(); v.mat_params = out.mat_params.data();
 	v.n_lights = (int)out.light_type.size(); v.light_type = out.light_type.data(); v.light_radiance = out.light_radiance.data(); v.light_prim = out.light_prim.data(); v.light_vec = out.light_vec.data();
 	v.world_radius = worldRadius;
-	v.bvh_reference_semantics = scene.referenceTree ? 1 : 0;
+	v.bvh_reference_semantics = scene.referenceTree ? (scene.certifiedWalk ? 2 : 1) : 0;
 	v.n_bvh_nodes = (int)out.bvh.left.size();                    // 0: hierarchy to be built on the device
 	v.bvh_bounds = out.bvh.bounds.data(); v.bvh_left = out.bvh.left.data(); v.bvh_right = out.bvh.right.data();
 	v.n_bvh_prim_indices = (int)out.bvh.prim_index.size(); v.bvh_prim_index = out.bvh.prim_index.data();

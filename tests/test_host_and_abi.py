@@ -21,7 +21,7 @@ def test_abi_exports_every_declared_symbol(H):
     lib = C.CDLL(H.jp.HIP_LIB_PATH)
     for n in names:
         assert hasattr(lib, n), "libjetpbrt_amd.so does not export %s" % n
-    assert lib.jp_abi_version() == 5
+    assert lib.jp_abi_version() == 6
 
 
 def test_abi_struct_layout_matches_header(H):
@@ -227,6 +227,25 @@ def test_reference_tree_builder_reproduces_the_reference_topology(H):
         assert n == len(kind), (n, len(kind))
         assert np.array_equal(ok[:n], np.array(kind, np.int32)) and np.array_equal(oo, np.array(order, np.int32))
         assert np.array_equal(ob[:n].view(np.uint32), np.array(boxes, np.float32).view(np.uint32))
+
+
+def test_certified_walk_flag_reaches_the_scene_record(H, monkeypatch):
+    """FScene::certifiedWalk: JpScene.bvh_reference_semantics 2 with the same (reference) tree as 1; also from the environment"""
+    def flat(**kw):
+        hb = H.scenes.HostBackend("misc")
+        if kw: hb.set_reference_tree(True, **kw)
+        H.SCENES["misc"](hb, 32, 24)
+        s = hb.flatten().contents
+        nn = s.n_bvh_nodes
+        return s.bvh_reference_semantics, np.ctypeslib.as_array(s.bvh_bounds, (nn * 6,)).copy(), np.ctypeslib.as_array(s.bvh_left, (nn,)).copy()
+    m1, b1, l1 = flat(certified=False)
+    m2, b2, l2_ = flat(certified=True)
+    assert (m1, m2) == (1, 2) and np.array_equal(b1, b2) and np.array_equal(l1, l2_)
+    monkeypatch.setenv("JETPBRT_REFERENCE_TREE", "2")
+    m3, b3, l3 = flat()
+    assert m3 == 2 and np.array_equal(b1, b3)
+    monkeypatch.setenv("JETPBRT_REFERENCE_TREE", "1")
+    assert flat()[0] == 1
 
 
 def test_libm_sincosf_transcription_matches_this_host(H):
