@@ -324,6 +324,7 @@ def main():
                 t1 = time.perf_counter()
                 ref = rctx.render(jp.render_params(W, H, spp_total, 5, 1234))
                 t_ref_gpu = time.perf_counter() - t1
+                t1 = time.perf_counter(); rctx.render(jp.render_params(W, H, spp_total, 5, 1234)); t_ref_warm = time.perf_counter() - t1   # (a second frame: without the allocations)
                 b = 17 if nbands > 17 else nbands // 2
                 # the link to the CPU oracle: rows spread over the whole image (2-row bands j with j % 30 == 8: ten tasks for ten
                 # oracle threads) at 192 spp, strictly compared
@@ -341,6 +342,24 @@ def main():
                 link_l2 = float(np.sqrt(((gband[lrows] - oband[lrows]) ** 2).sum(-1)).mean())
             finally:
                 rctx.close()
+            # the certified walk over the same (reference) tree -- FScene::certifiedWalk, DESIGN.md "Certified walk": speed, and how far its film is from the verbatim one
+            certified = None
+            cb = scenes.HostBackend("bench_cert")
+            cb.set_reference_tree(True, certified=True)
+            build_scene(scenes, cb, scene_key, W, H)
+            cctx = jp.Context(dev)
+            try:
+                cctx.upload(cb.flatten())
+                pf = jp.render_params(W, H, spp_total, 5, 1234)
+                cctx.render(pf)                               # allocations, lanes
+                t1 = time.perf_counter(); cfilm = cctx.render(pf); t_c = time.perf_counter() - t1
+                cc = cctx.counters(); cbi = cctx.build_info()
+                dc = np.sqrt(((cfilm - ref) ** 2).sum(-1))
+                certified = {"Msamples_s": round(W * H * spp_total / t_c / 1e6, 1), "verbatim_Msamples_s": round(W * H * spp_total / t_ref_warm / 1e6, 1),
+                             "mean_per_pixel_l2_vs_verbatim": float(dc.mean()), "fraction_pixels_identical": float((cfilm == ref).all(-1).mean()),
+                             "rays_walked_again": int(cc.certified_fallback_rays), "rays": int(cc.closest_rays + cc.shadow_rays), "nodes": int(cbi.certified_nodes), "on": bool(cbi.certified_walk)}
+            finally:
+                cctx.close()
             d = np.sqrt(((film - ref) ** 2).sum(-1))
             band = d[b * 20:b * 20 + 20]
             parity = {"mean_per_pixel_l2": float(d.mean()), "max_per_pixel_l2": float(d.max()), "pixels": int(d.size), "spp": spp_total,
@@ -350,6 +369,7 @@ def main():
                       "fraction_pixels_identical": float((film == ref).all(-1).mean()), "fraction_pixels_gt_1e-3": float((d > 1e-3).mean()),
                       "band_through_meshes": {"band": b, "mean_per_pixel_l2": float(band.mean()), "fraction_pixels_identical": float((film[b * 20:b * 20 + 20] == ref[b * 20:b * 20 + 20]).all(-1).mean())},
                       "note": "the default path walks its own SAH tree: ~3e-4 of the samples through the meshes find a different first hit than the reference's rand()-driven tree does (fringe hits, DESIGN.md Numerics)",
+                      "certified_walk": certified,
                       "libm_sincosf": int(bi.libm_sincosf)}
             cpu_spp = 4
         # CPU baseline: the whole frame at a reduced spp (throughput does not depend on spp), 20-row tasks, stock sampler
@@ -417,7 +437,9 @@ def main():
                 "dominant": v["roofline"]["kernel"], "frac": v["roofline"]["frac"],
                 "l2": (None if not v.get("l2_vs_cpu_ref") else r4(v["l2_vs_cpu_ref"]["mean_per_pixel_l2"])),
                 "identical": (None if not v.get("l2_vs_cpu_ref") else (v["l2_vs_cpu_ref"].get("bit_identical") if "bit_identical" in v["l2_vs_cpu_ref"] else round(v["l2_vs_cpu_ref"].get("fraction_pixels_identical", 0), 4))),
-                "cpu_ref_Msamples_s": (None if not v.get("cpu_baseline") else v["cpu_baseline"]["value"])} for k, v in subs.items()}
+                "cpu_ref_Msamples_s": (None if not v.get("cpu_baseline") else v["cpu_baseline"]["value"]),
+                **({"certified": {"Msamples_s": v["l2_vs_cpu_ref"]["certified_walk"]["Msamples_s"], "l2_vs_verbatim": r4(v["l2_vs_cpu_ref"]["certified_walk"]["mean_per_pixel_l2_vs_verbatim"]),
+                                  "identical": round(v["l2_vs_cpu_ref"]["certified_walk"]["fraction_pixels_identical"], 6)}} if (v.get("l2_vs_cpu_ref") or {}).get("certified_walk") else {})} for k, v in subs.items()}
             # the full sub-records (roofline, cpu_baseline, l2_vs_cpu_ref of every config) go to stderr: the ONE line on stdout stays
             # small enough for a log tail to keep whole, with every sub-record's figures in config.sub
             sys.stderr.write("configs_detail " + json.dumps(subs, separators=(",", ":")) + "\n"); sys.stderr.flush()

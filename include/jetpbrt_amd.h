@@ -108,9 +108,10 @@ typedef struct JpScene {
      * 2: (ABI 6) REFERENCE SEMANTICS, CERTIFIED WALK -- scenes of more than 1024 primitives: the rays take an ordered walk over the LEAVES
      *    of the given tree; each result carries a proof that the walk of (1) returns the same hit (FBounds3::Intersect on the hit's leaf
      *    box with max_t = the hit distance implies the same for every ancestor and every larger max_t), and the rays without a proof are
-     *    walked again as in (1).  About twice as fast as (1).  Not strictly identical to (1): a ray within fp32 noise of a triangle's
-     *    plane is accepted or not by the signs of rounding errors, wherever along the ray that triangle lies, and only (1) visits all of
-     *    those (DESIGN.md "Certified walk": about one camera ray in 10^6 on the 280k-triangle scene).  Smaller scenes: as (1). */
+     *    walked again as in (1).  About twice as fast as (1).  One class of rays is outside the proof: a ray within fp32 noise of a
+     *    triangle's plane is accepted or not by the signs of rounding errors, wherever along the ray that triangle lies.  Rays from the camera
+     *    position are covered (leaves with a primitive edge-on to the camera are never culled by distance for them); for secondary rays there is
+     *    only the measurement: the 280k-triangle frame at 800x600x2048 is bit-identical to (1) (DESIGN.md "Certified walk").  Smaller scenes: as (1). */
     int32_t bvh_reference_semantics;
 
     /* FDisk (shape.h:189-275): position, normal (already normalised by the constructor, shape.h:194), radius */
@@ -170,6 +171,8 @@ typedef struct JpBuildInfo {
                                     carry a proof that FBVH_Node::Intersect returns the same hit; the few that cannot are walked again verbatim
                                     (DESIGN.md "Certified walk"; JETPBRT_CERTIFIED=0: every ray verbatim, as in ABI <= 5) */
     int32_t certified_nodes;     /* nodes of the 4-wide tree over the caller's leaves */
+    int32_t certified_eye_leaves;/* leaves of the caller's tree holding a primitive whose plane passes through the camera position (within 5e-3 of its distance):
+                                    camera rays are not culled by distance there (DESIGN.md "Certified walk") */
 } JpBuildInfo;
 
 typedef struct JpContext JpContext;

@@ -64,7 +64,7 @@ class JpCounters(C.Structure):
 class JpBuildInfo(C.Structure):
     _fields_ = [("built_on_device", C.c_int32), ("traversal_mode", C.c_int32), ("bvh_nodes", C.c_int32), ("bvh_height", C.c_int32),
                 ("device_build_ms", C.c_double), ("libm_sincosf", C.c_int32), ("lanes_last_render", C.c_int32),
-                ("fused_last_render", C.c_int32), ("fused_region", C.c_int32), ("fused_workgroups", C.c_int32), ("q4_nodes", C.c_int32), ("libm_xbsdf", C.c_int32), ("certified_walk", C.c_int32), ("certified_nodes", C.c_int32)]
+                ("fused_last_render", C.c_int32), ("fused_region", C.c_int32), ("fused_workgroups", C.c_int32), ("q4_nodes", C.c_int32), ("libm_xbsdf", C.c_int32), ("certified_walk", C.c_int32), ("certified_nodes", C.c_int32), ("certified_eye_leaves", C.c_int32)]
 
 
 JP_INTEGRATOR_PATH, JP_INTEGRATOR_WHITTED, JP_INTEGRATOR_DEBUG_NORMAL = 0, 1, 2

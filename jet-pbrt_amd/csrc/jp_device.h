@@ -604,9 +604,12 @@ template <> struct Walker<3>
 // Shadow rays: any accepted hit with a passing certificate means the reference's walk ends occluded; none found means visible.
 template <bool kCert> struct WalkerQ4
 {
-	V3 o, d; float ix, iy, iz, tmin, tmax; int cur, sp, hit; bool done, unsure;
+	V3 o, d; float ix, iy, iz, tmin, tmax; int cur, sp, hit; bool done, unsure, from_eye;
 	__device__ __forceinline__ void start(V3 o_, V3 d_, float tmin_, float tmax_)
-	{ o = o_; d = d_; ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z; tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; done = false; unsure = kCert && (d.x == 0.f || d.y == 0.f || d.z == 0.f); }
+	{ o = o_; d = d_; ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z; tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; done = false; unsure = kCert && (d.x == 0.f || d.y == 0.f || d.z == 0.f); from_eye = false; }
+	// kCert: a ray that starts at the camera position is not culled by distance at the children flagged "edge-on to the camera" (jp_upload_scene): the
+	// triangles whose plane passes through the eye are the ones a camera ray can lie in to within fp32 noise (see above)
+	__device__ __forceinline__ void mark_origin(const SceneView& sc) { from_eye = kCert && o.x == sc.cam.pos[0] && o.y == sc.cam.pos[1] && o.z == sc.cam.pos[2]; }
 	__device__ __forceinline__ bool heavy() const { return cur < 0; }                 // next step is a leaf (primitive tests), not a node
 	// FBounds3::Intersect (geometry.cc:10-30) on the reference leaf box of primitive p with max_t = t
 	__device__ __forceinline__ bool leaf_box_passes(const SceneView& sc, int p, float t) const
@@ -620,6 +623,7 @@ template <bool kCert> struct WalkerQ4
 		{
 			const uint4* __restrict__ nd = sc.q4 + 4 * (size_t)cur;
 			const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2]; const uint2 q3 = *(const uint2*)(nd + 3);
+			const unsigned int eyebits = kCert ? ((const unsigned int*)(nd + 3))[2] : 0u;
 			// slab distance of plane byte q on axis x: ((p.x + q * 2^e.x) - o.x) / d.x = q * A.x + B.x with A = 2^e / d, B = (p - o) / d: one
 			// conversion and one fma per plane.  Rounding: |error| <~ 3e-7 * (node extent) / |d| -- covered by the host's padding of every child
 			// box by 1e-6 of the node's extent before it is quantised outward (jp_upload_scene), on top of the 2e-6 relative slack below.
@@ -633,6 +637,7 @@ template <bool kCert> struct WalkerQ4
 			const unsigned int azn = nz ? q2.z : q3.y, azf = nz ? q3.y : q2.z;
 			float tn[4]; bool hc[4]; int nh = 0;
 			const float tcull = kCert ? fmaf(sc.cert_pad * tmax, tmax, tmax) : tmax;
+			const float tcull_eye = (kCert && from_eye) ? JP_INF : tcull;                  // for the children with the edge-on flag (bits 0..3 of q3.z)
 			#pragma unroll
 			for (int i = 0; i < 4; i++)
 			{
@@ -641,7 +646,7 @@ template <bool kCert> struct WalkerQ4
 				const float y0 = fmaf((float)((ayn >> sh) & 0xffu), ay, by), y1 = fmaf((float)((ayf >> sh) & 0xffu), ay, by);
 				const float z0 = fmaf((float)((azn >> sh) & 0xffu), az, bz), z1 = fmaf((float)((azf >> sh) & 0xffu), az, bz);
 				const float t0 = fmaxf(fmaxf(x0, y0), fmaxf(z0, tmin));
-				const float tf = fminf(fminf(x1, y1), fminf(z1, tcull));
+				const float tf = fminf(fminf(x1, y1), fminf(z1, (kCert && ((eyebits >> i) & 1u)) ? tcull_eye : tcull));
 				hc[i] = ((q0.w >> (24 + i)) & 1u) && t0 <= tf * 1.000002f;
 				tn[i] = hc[i] ? fminf(t0, 3.0e38f) : JP_INF;             // a missed child ranks behind every hit one
 				nh += hc[i] ? 1 : 0;
@@ -716,7 +721,7 @@ __device__ __forceinline__ int walk_ray(const SceneView& sc, V3 o, V3 d, float t
 {
 	if constexpr (kMode == 6)
 	{   // certified walk; an unsure ray is walked again the reference's way
-		Walker<6> w; w.start(o, d, tmin, tmax);
+		Walker<6> w; w.start(o, d, tmin, tmax); w.mark_origin(sc);
 		while (!w.done) w.template step<kAnyHit>(sc, stack);
 		if (kAnyHit ? (w.hit >= 0 || !w.unsure) : w.certain(sc)) { tmax = w.tmax; return w.hit; }
 		return walk_ray<5, kAnyHit>(sc, o, d, tmin, tmax, stack);

@@ -860,6 +860,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queue
 				{
 					const float4 ro = q.ray_o[cur_q][rbase + my], rd = q.ray_d[cur_q][rbase + my];
 					w.start(xyz(ro), xyz(rd), 0.001f, JP_INF);       // FRay defaults geometry.h:399
+					if constexpr (kMode == 6) w.mark_origin(sc);
 					ridx = my;
 				}
 			}
@@ -1358,7 +1359,7 @@ struct JpContext
 	// stream of the lane (own spill area) and run beside the next extend launch; the next k_shade waits for both
 	bool dual = false; hipStream_t stream2 = nullptr; hipEvent_t ev_shade = nullptr, ev_shadow = nullptr; int* d_spill2 = nullptr; size_t spill2_words = 0;
 	size_t trav_lds_pad = 0;                                                           // experiment: extra dynamic LDS of the refill kernels = fewer of their workgroups per CU (room for another lane's k_shade)
-	void* d_refbox = nullptr; bool cert = false;                                       // reference semantics, certified walk (Walker<6>): leaf boxes per primitive
+	void* d_refbox = nullptr; bool cert = false; int cert_eye_leaves = 0;                                       // reference semantics, certified walk (Walker<6>): leaf boxes per primitive
 	bool use_q4 = false, q4_shadow = false;                                            // closest-hit (and, as an experiment, shadow) rays walk the 4-wide quantised tree (Walker<4>)
 	bool vote = false; int persist = 0;                                             // lane refill in the closest-hit traversal of large scenes (k_extend_persist): refill threshold, 0 = off
 	void *d_nodes = nullptr, *d_prims = nullptr, *d_meta = nullptr, *d_mats = nullptr, *d_mat_type = nullptr, *d_lights = nullptr, *d_shade_tab = nullptr;
@@ -1970,7 +1971,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	// From binary node b: its two children, then the interior child with the largest box is opened again while fewer than four
 	// slots are taken.  Leaves keep the binary tree's encoding and primitive records.  JETPBRT_Q4=0: closest hits walk the binary tree.
 	// (one collapse for two sources: the caller's tree as it is, and -- reference semantics, certified walk -- the tree built below over the caller's leaves)
-	auto collapse_q4 = [&](size_t n_nodes, auto isInner, auto leftOf, auto rightOf, auto boxOf, auto leafRefOf, std::vector<uint32_t>& q4, int& q4_height) -> bool
+	auto collapse_q4 = [&](size_t n_nodes, auto isInner, auto leftOf, auto rightOf, auto boxOf, auto leafRefOf, auto flagOf, std::vector<uint32_t>& q4, int& q4_height) -> bool
 	{
 		struct Item { int bnode; uint32_t idx; int depth; };
 		auto area = [](const float* b) { float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2]; return dx * dy + dy * dz + dz * dx; };
@@ -2012,12 +2013,13 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 				e = std::max(-120, std::min(120, e));
 				eb[a] = e + 127; sc3[a] = std::ldexp(1.0f, e);
 			}
-			uint8_t ql[3][4], qh[3][4]; uint32_t refs[4] = { 0, 0, 0, 0 }, valid = 0;
+			uint8_t ql[3][4], qh[3][4]; uint32_t refs[4] = { 0, 0, 0, 0 }, valid = 0, flags = 0;
 			for (int k = 0; k < 4; k++) for (int a = 0; a < 3; a++) { ql[a][k] = 255; qh[a][k] = 0; }
 			for (int k = 0; k < nc && ok; k++)
 			{
 				valid |= 1u << k;
 				const int n = ch[k];
+				if (flagOf(n)) flags |= 1u << k;
 				int r;
 				if (isInner(n)) { r = (int)(q4.size() / 16); queue.push_back({ n, (uint32_t)r, it.depth + 1 }); q4.resize(q4.size() + 16, 0u); }
 				else r = leafRefOf(n);
@@ -2039,7 +2041,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 			w[3] = (uint32_t)eb[0] | ((uint32_t)eb[1] << 8) | ((uint32_t)eb[2] << 16) | (valid << 24);
 			w[4] = refs[0]; w[5] = refs[1]; w[6] = refs[2]; w[7] = refs[3];
 			w[8] = pack4(ql[0]); w[9] = pack4(ql[1]); w[10] = pack4(ql[2]); w[11] = pack4(qh[0]);
-			w[12] = pack4(qh[1]); w[13] = pack4(qh[2]); w[14] = 0; w[15] = 0;
+			w[12] = pack4(qh[1]); w[13] = pack4(qh[2]); w[14] = flags; w[15] = 0;
 		}
 		return ok;
 	};
@@ -2049,7 +2051,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	if (use_q4)
 	{
 		const bool ok = collapse_q4((size_t)s->n_bvh_nodes, [&](int n) { return s->bvh_left[n] >= 0; }, [&](int n) { return s->bvh_left[n]; }, [&](int n) { return s->bvh_right[n]; },
-		                            [&](int n, float* bb) { pad_box(n, bb); }, [&](int n) { return emit_leaf(n); }, q4, q4_height);
+		                            [&](int n, float* bb) { pad_box(n, bb); }, [&](int n) { return emit_leaf(n); }, [](int) { return false; }, q4, q4_height);
 		if (!ok || (int)meta.size() != s->n_primitives) { use_q4 = false; q4.clear(); }
 	}
 
@@ -2077,8 +2079,25 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 		};
 		bool ok = it.left[0] >= 0 && it.height + 2 <= 48;
 		for (int i = 0; i < ni && ok; i++) if (cert_item_cnt[i] < 1 || cert_item_cnt[i] > 16) ok = false;
+		// "edge-on to the camera": a leaf holding a flat primitive whose plane passes the eye within tau of its distance -- the only primitives a CAMERA ray can
+		// lie in to within fp32 noise, i.e. whose acceptance far in front of their leaf's box an ordered walk would cull (Walker<6>).  Flag = leaf, and every node above it.
+		float tau = 5e-3f; if (const char* e = getenv("JETPBRT_CERT_EYE")) tau = std::max(0.f, (float)atof(e));
+		std::vector<char> item_eye(ni, 0), node_eye(it.left.size(), 0); int n_eye = 0;
+		for (int i = 0; i < ni && ok; i++)
+			for (int k = 0; k < cert_item_cnt[i]; k++)
+			{
+				const size_t p = (size_t)cert_item_first[i] + k;
+				int type; std::memcpy(&type, &prims[4 * p + 3].w, 4);
+				if (type == JP_SHAPE_SPHERE) continue;
+				const float4 g0 = prims[4 * p], gn = type == JP_SHAPE_DISK ? prims[4 * p + 1] : prims[4 * p + 3];
+				const double vx = (double)g0.x - s->camera.pos[0], vy = (double)g0.y - s->camera.pos[1], vz = (double)g0.z - s->camera.pos[2];
+				const double nl = std::sqrt((double)gn.x * gn.x + (double)gn.y * gn.y + (double)gn.z * gn.z), dist = std::sqrt(vx * vx + vy * vy + vz * vz);
+				if (std::fabs(vx * gn.x + vy * gn.y + vz * gn.z) <= tau * dist * nl + 1e-30) { if (!item_eye[i]) n_eye++; item_eye[i] = 1; }
+			}
+		if (ok) for (size_t n = it.left.size(); n-- > 0;) node_eye[n] = it.left[n] < 0 ? item_eye[-it.left[n] - 1] : (char)(node_eye[it.left[n]] | node_eye[it.right[n]]);   // children have higher indices than their parent
+		c->cert_eye_leaves = n_eye;
 		if (ok) ok = collapse_q4(it.left.size(), [&](int n) { return it.left[n] >= 0; }, [&](int n) { return it.left[n]; }, [&](int n) { return it.right[n]; }, box_of,
-		                         [&](int n) { const int item = -it.left[n] - 1; return -(((cert_item_first[item] << 4) | (cert_item_cnt[item] - 1)) + 1); }, q4, q4_height);
+		                         [&](int n) { const int item = -it.left[n] - 1; return -(((cert_item_first[item] << 4) | (cert_item_cnt[item] - 1)) + 1); }, [&](int n) { return node_eye[n] != 0; }, q4, q4_height);
 		if (!ok) { use_cert = false; q4.clear(); }
 		else
 		{
@@ -2942,7 +2961,7 @@ int jp_get_build_info(JpContext* c, JpBuildInfo* out)
 	out->device_build_ms = c->build_ms; out->libm_sincosf = c->sincosf_mode; out->lanes_last_render = c->last_lanes;
 	out->fused_last_render = c->last_fused; out->fused_region = c->last_region; out->fused_workgroups = c->last_wgs;
 	out->q4_nodes = c->use_q4 ? c->sv.n_q4 : 0; out->libm_xbsdf = c->libm_mode;
-	out->certified_walk = c->cert ? 1 : 0; out->certified_nodes = c->cert ? c->sv.n_q4 : 0;
+	out->certified_walk = c->cert ? 1 : 0; out->certified_nodes = c->cert ? c->sv.n_q4 : 0; out->certified_eye_leaves = c->cert ? c->cert_eye_leaves : 0;
 	return JP_OK;
 }
 

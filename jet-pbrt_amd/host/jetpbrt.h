@@ -350,9 +350,9 @@ public:
 	bool referenceTree = false;
 	// With referenceTree: the CERTIFIED walk (JpScene.bvh_reference_semantics = 2; DESIGN.md "Certified walk") -- an ordered walk over the leaves
 	// of the reference's tree that proves, ray by ray, that FBVH_Node::Intersect returns the same hit, and repeats the few rays it cannot prove
-	// the reference's way.  About twice as fast as the verbatim walk on large meshes; NOT strictly identical: a ray that lies within fp32
-	// noise of a triangle's plane is decided in the reference by the signs of rounding errors wherever that triangle is, and only the verbatim walk
-	// sees all of those (measured: about one camera ray in 10^6).  Default from env JETPBRT_REFERENCE_TREE=2.
+	// the reference's way.  About twice as fast as the verbatim walk on large meshes.  Outside the proof: a ray that lies within fp32 noise of a
+	// triangle's plane is decided in the reference by the signs of rounding errors wherever that triangle is; camera rays are covered by flags on the
+	// leaves edge-on to the camera, secondary rays only by measurement (the 280k-triangle frame is bit-identical).  Default from env JETPBRT_REFERENCE_TREE=2.
 	bool certifiedWalk = false;
 };
 

@@ -48,7 +48,7 @@ def main():
             print("%-44s %s %dx%dx%d: %7.1f Msamples/s (%s) | 1 lane: %7.1f ms  path %.2f extend %.2f shade %.2f shadow %.2f other %.2f | rays %d/%d | film %s" % (
                 v or "(default)", name, W, Hh, spp, W * Hh * spp / dt / 1e6, sched, c.render_ms, c.path_ms, c.extend_ms, c.shade_ms, c.shadow_ms, c.other_ms,
                 c.closest_rays, c.shadow_rays, same + " sha1 " + hashlib.sha1(film.tobytes()).hexdigest()[:12])
-                + ((" | certified walk: %d nodes, %d rays walked again" % (bi.certified_nodes, c.certified_fallback_rays)) if bi.certified_walk else ""), flush=True)
+                + ((" | certified walk: %d nodes, %d edge-on leaves, %d rays walked again" % (bi.certified_nodes, bi.certified_eye_leaves, c.certified_fallback_rays)) if bi.certified_walk else ""), flush=True)
             ctx.close()
         finally:
             for k in kv:

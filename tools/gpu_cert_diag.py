@@ -40,7 +40,7 @@ def compare(tag, ref, got):
 
 ref = trace({"JETPBRT_TRACE_VERBATIM": "1"}, o, d, tmax)
 bad = None
-for env in ({}, {"JETPBRT_CERT_SLACK": "0"}, {"JETPBRT_CERT_SLACK": "1024"}, {"JETPBRT_CERT_SLACK": "1024", "JETPBRT_BOX_PAD": "0.01"}):
+for env in ({}, {"JETPBRT_CERT_EYE": "0"}, {"JETPBRT_CERT_EYE": "0", "JETPBRT_CERT_SLACK": "0"}, {"JETPBRT_CERT_EYE": "0.05"}):
     got = trace(env, o, d, tmax)
     idx = compare("camera " + (" ".join("%s=%s" % (k[8:], v) for k, v in env.items()) or "(default)"), ref, got)
     if bad is None:
@@ -57,7 +57,7 @@ d2 = (N + r).astype(np.float32); d2 /= np.maximum(np.linalg.norm(d2, axis=1, kee
 o2 = P.astype(np.float32); d2 = d2.astype(np.float32); k = len(o2)
 tm2 = np.full(k, np.inf, np.float32)
 ref2 = trace({"JETPBRT_TRACE_VERBATIM": "1"}, o2, d2, tm2)
-for env in ({}, {"JETPBRT_CERT_SLACK": "0"}, {"JETPBRT_CERT_SLACK": "1024"}):
+for env in ({}, {"JETPBRT_CERT_SLACK": "0"}):
     got = trace(env, o2, d2, tm2)
     idx = compare("secondary " + (" ".join("%s=%s" % (k_[8:], v) for k_, v in env.items()) or "(default)"), ref2, got)
     for i in idx[:6]:
