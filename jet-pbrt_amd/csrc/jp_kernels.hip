@@ -2662,6 +2662,7 @@ bool fused_eligible(const JpContext* c, const JpRenderParams* rp)
 	if (!e || atoi(e) == 0) return false;
 	if (c->is_lane || !c->have_scene || rp->integrator != JP_INTEGRATOR_PATH) return false;
 	if (!c->tables_in_lds || c->n_planes > 4) return false;          // (its own LDS budget: render_fused shrinks the region until the layout fits)
+	if (c->cert) return false;                                       // the certified walk lives in the per-bounce traversal kernels
 	if (c->trav_mode == 2) return c->shade_prims_in_lds;
 	return c->trav_mode == 0 || c->trav_mode == 3 || c->trav_mode == 5;
 }
