@@ -695,6 +695,38 @@ def test_reference_tree_large_scene_band_bit_identical(H, gpu_ctx):
 
 
 
+def test_certified_walk_small_mesh_against_the_oracle(H, gpu_ctx):
+    """the certified walk pinned to the CPU oracle directly (not through the device's verbatim walk): the committed 2,882-triangle mesh scene with the
+    reference's tree -- 100,000 random rays (any origin, half of them with a finite max_t, 2,000 parallel to a coordinate plane) and a film, strictly equal"""
+    W, Hh, spp = 120, 90, 16
+    hb = H.scenes.HostBackend("bunny_small"); hb.set_reference_tree(True, certified=True); H.SCENES["bunny_small"](hb, W, Hh); sp = hb.flatten()
+    gpu_ctx.upload(sp)
+    bi = gpu_ctx.build_info()
+    assert bi.traversal_mode == 5 and bi.certified_walk == 1 and bi.certified_nodes > 50
+    rng = np.random.default_rng(9)
+    m = 100000
+    o = (rng.random((m, 3)) * [500, 300, 500] - [250, -10, 250]).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:2000, 1] = 0.0
+    tmin = np.full(m, 0.001, np.float32); tmax = np.where(rng.random(m) < 0.5, np.inf, rng.random(m) * 400).astype(np.float32)
+    hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
+    H.libc_srand(1)
+    ohit, ot, oprim, onrm = _oracle_trace(H, sp, o, d, tmin, tmax)
+    assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)) and np.array_equal(prim, oprim)
+    assert np.array_equal(nrm.view(np.uint32), onrm.view(np.uint32))
+    p = H.jp.render_params(W, Hh, spp, 5, 4321)
+    film = gpu_ctx.render(p)
+    c = gpu_ctx.counters()
+    H.libc_srand(1)
+    ref, cnt = H.oracle_render(sp, p, 8)
+    if bi.libm_sincosf != 0:
+        assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)), (l2(film, ref), (film == ref).all(-1).mean())
+        assert (c.closest_rays, c.closest_hits, c.shadow_rays, c.shadow_occluded) == (cnt.closest_rays, cnt.closest_hits, cnt.shadow_rays, cnt.shadow_occluded)
+    else:
+        assert l2(film, ref) < TOL_L2
+    assert c.certified_fallback_rays < 0.05 * (c.closest_rays + c.shadow_rays)
+
+
 def test_certified_walk_against_the_verbatim_walk(H, gpu_ctx):
     """FScene::certifiedWalk (JpScene.bvh_reference_semantics 2, DESIGN.md "Certified walk") on the 280k-triangle scene: an ordered walk over
     the leaves of the reference's tree whose every result carries a proof that FBVH_Node::Intersect returns the same hit; rays without a
