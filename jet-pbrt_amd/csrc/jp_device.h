@@ -602,6 +602,13 @@ template <> struct Walker<3>
 //  * two accepted hits at the same distance (the reference keeps whichever it reaches first), a certificate that fails, a ray parallel to
 //    an axis: the ray is UNSURE and is walked again the reference's way (Walker<5>) -- a few rays in 10^4.
 // Shadow rays: any accepted hit with a passing certificate means the reference's walk ends occluded; none found means visible.
+#ifdef JP_WALK_STATS
+// diagnostic builds only (tools/walk_stats.py): node steps, leaf steps, primitive tests, stack pushes of the 4-wide walks -- [0..3] closest-hit rays, [4..7] shadow rays
+__device__ unsigned long long g_walk_stats[8];
+#define JP_WS(i, v) atomicAdd(&g_walk_stats[(kAnyHit ? 4 : 0) + (i)], (unsigned long long)(v))
+#else
+#define JP_WS(i, v) do { } while (0)
+#endif
 template <bool kCert> struct WalkerQ4
 {
 	V3 o, d; float ix, iy, iz, tmin, tmax; int cur, sp, hit; bool done, unsure, from_eye;
@@ -684,10 +691,12 @@ template <bool kCert> struct WalkerQ4
 			}
 			sp += nh > 0 ? nh - 1 : 0;
 			pop = nh == 0;
+			JP_WS(0, 1); JP_WS(3, nh > 0 ? nh - 1 : 0);
 		}
 		else
 		{   // one leaf per step (Walker<0>)
 			const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
+			JP_WS(1, 1); JP_WS(2, count);
 			if (kCert)
 			{
 				for (int k = 0; k < count; k++)

@@ -3047,6 +3047,16 @@ extern "C" int jp_dbg_shade_timing(unsigned long long* out16)
 }
 #endif
 
+#ifdef JP_WALK_STATS
+extern "C" int jp_dbg_walk_stats(unsigned long long* out8)
+{
+	unsigned long long z[8] = { 0 };
+	if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(jp::g_walk_stats), sizeof(z)) != hipSuccess) return -1;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(jp::g_walk_stats), z, sizeof(z)) != hipSuccess) return -1;
+	return 0;
+}
+#endif
+
 #ifdef JP_PATH_TIMING
 extern "C" int jp_dbg_path_timing(unsigned long long* out16)
 {
