@@ -789,6 +789,13 @@ def test_certified_walk_against_the_verbatim_walk(H, gpu_ctx):
     assert 0 < c.certified_fallback_rays < 2e-3 * rays
     assert (film == vfilm).all(-1).mean() > 0.99999 and d_.mean() < 1e-7
     assert abs(int(c.closest_rays) - int(vc.closest_rays)) < 1e-5 * vc.closest_rays
+    # a band shard (the multi-GPU unit) of the certified film equals those rows of the whole film
+    ps3 = H.jp.render_params(W, Hh, 16, shard_index=1, shard_count=3)
+    shard = gpu_ctx.render(ps3)
+    rows = np.zeros(Hh, bool)
+    for y0, y1 in H.jp.distributed.bands_of(Hh, 1, 3):
+        rows[y0:y1] = True
+    assert np.array_equal(shard[rows].view(np.uint32), film[rows].view(np.uint32)) and np.abs(shard[~rows]).max() == 0
     # a scene below the size where the ordered walk pays: the flag is accepted and every ray takes the verbatim walk
     sb = H.scenes.HostBackend("misc"); sb.set_reference_tree(True, certified=True); H.SCENES["misc"](sb, 96, 72)
     gpu_ctx.upload(sb.flatten())
