@@ -11,6 +11,7 @@ jp = H.jp
 
 
 def timed(ctx, p, reps=3):
+    if p.spp > 1024: reps = 1
     ctx.render(p)
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -20,12 +21,12 @@ def timed(ctx, p, reps=3):
 
 def main():
     ctx = jp.Context(0)
-    for name, W, Hh, spp in (("cornell", 512, 512, 1024), ("bunny", 1920, 1080, 512)):
+    for name, W, Hh, spp in (("cornell", 512, 512, 1024), ("bunny", 1920, 1080, 512), ("bunny", 1920, 1080, 4096)):   # the last: BASELINE.json configs[4] at its own sample count
         hb = H.scenes.build_bunny(H.scenes.HostBackend("s"), W, Hh) if name == "bunny" else H.SCENES[name](H.scenes.HostBackend("s"), W, Hh)
         ctx.upload(hb.flatten())
         t1 = timed(ctx, jp.render_params(W, Hh, spp, band_rows=jp.distributed.balanced_band_rows(Hh, 1)))
         print("%s %dx%dx%d: whole frame %.1f ms (%.0f Msamples/s)" % (name, W, Hh, spp, t1 * 1e3, W * Hh * spp / t1 / 1e6), flush=True)
-        for n in (2, 4, 8):
+        for n in ((8,) if spp > 1024 else (2, 4, 8)):
             band = jp.distributed.balanced_band_rows(Hh, n)
             ts = [timed(ctx, jp.render_params(W, Hh, spp, band_rows=band, shard_index=r, shard_count=n)) for r in (0, n - 1)]
             tn = max(ts)
