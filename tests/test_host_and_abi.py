@@ -306,6 +306,8 @@ def test_kernel_register_budgets(H, tmp_path):
     for name in ("k_extend<2>", "k_extend<0>", "k_extend_persist<0, 16, true>", "k_shadow_persist<3, 16, true>", "k_extend_persist<5, 16, false>",
                  "k_extend_persist<4, 16, true>", "k_shadow_persist<4, 16, true>"):
         assert rows[name]["vgpr"] <= 64 and rows[name]["waves"] == 8 and rows[name]["scratch"] == 0, (name, rows[name])
+    for name in ("k_extend_persist<6, 16, true>", "k_shadow_persist<6, 16, true>"):      # the certified walk: the 4-wide walk + certificate + the verbatim walk behind it
+        assert rows[name]["vgpr"] <= 72 and rows[name]["waves"] >= 7 and rows[name]["scratch"] == 0, (name, rows[name])
     assert rows["k_shadow<2>"]["waves"] >= 6
     # (k_path, the opt-in fused schedule: register allocation aimed at 3 waves per SIMD, a few phase-level values spill outside its inner loops)
     assert all(r["waves"] >= 3 for n, r in rows.items() if n.startswith("k_path"))
