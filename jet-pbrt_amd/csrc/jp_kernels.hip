@@ -3020,7 +3020,7 @@ int jp_trace(JpContext* c, int32_t n, const float* origin, const float* dir, con
 		hipMemcpyAsync(d_t0, tmin, (size_t)n * 4, hipMemcpyHostToDevice, c->stream); hipMemcpyAsync(d_t1, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
 		int grid = std::min(c->n_cus * 8, (n + JP_BLOCK - 1) / JP_BLOCK);
 		if (c->trav_mode == 3 && getenv("JETPBRT_TRACE_WIDE")) hipLaunchKernelGGL(k_trace<3>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes_shadow, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
-		else if (c->trav_mode == 5 && c->cert && !getenv("JETPBRT_TRACE_VERBATIM")) hipLaunchKernelGGL(k_trace<6>, dim3(grid), dim3(JP_BLOCK), (size_t)c->stack_depth * JP_BLOCK * sizeof(int), c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
+		else if (c->trav_mode == 5 && c->cert && (size_t)c->stack_depth * JP_BLOCK * sizeof(int) <= 64 * 1024 && !getenv("JETPBRT_TRACE_VERBATIM")) hipLaunchKernelGGL(k_trace<6>, dim3(grid), dim3(JP_BLOCK), (size_t)c->stack_depth * JP_BLOCK * sizeof(int), c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		else if (c->trav_mode == 5) hipLaunchKernelGGL(k_trace<5>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		else if (c->use_q4 && !getenv("JETPBRT_TRACE_BINARY")) hipLaunchKernelGGL(k_trace<4>, dim3(grid), dim3(JP_BLOCK), (size_t)c->stack_depth * JP_BLOCK * sizeof(int), c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
 		else if (c->trav_mode == 2) hipLaunchKernelGGL(k_trace<2>, dim3(grid), dim3(JP_BLOCK), c->lds_bytes, c->stream, c->sv, c->stack_depth, n, d_o, d_d, d_t0, d_t1, d_hit, d_t, d_prim, d_n);
