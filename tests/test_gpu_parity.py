@@ -931,7 +931,7 @@ def test_config3_full_size_default_path_vs_reference_tree(H, gpu_ctx):
     finally:
         rctx.close()
     # the certified walk over the same tree (FScene::certifiedWalk) at the full size against the verbatim film: bit-identical when measured
-    # (3.3e9 rays); asserted as "at most 5 pixels of 480,000 differ, each minutely", the level without the edge-on flags
+    # (3.3e9 rays); asserted as "at most 5 pixels of 480,000 differ, each minutely", the level of the first version (no edge-on flags, cull slack K = 1024)
     cb = H.scenes.HostBackend("bunny"); cb.set_reference_tree(True, certified=True); H.scenes.build_bunny(cb, W, Hh)
     cctx = H.jp.Context(0)
     try:
@@ -982,6 +982,18 @@ def test_config4_one_shard_of_eight_full_spp_and_shard_union(H, gpu_ctx):
     d = np.sqrt(((film[rows] - ref[rows]) ** 2).sum(-1))
     print("configs[4] shard 0/8 (135 rows of 1920x1080) at 4096 spp: mean L2 %.3e (gate 1e-4), identical px %.4f, px > 1e-3: %.4f" % (d.mean(), (film[rows] == ref[rows]).all(-1).mean(), (d > 1e-3).mean()))
     assert d.mean() < TOL_L2, d.mean()
+    # the same shard through the certified walk (FScene::certifiedWalk): the verbatim film, up to a few pixels at most (measured: none)
+    cb = H.scenes.HostBackend("bunny"); cb.set_reference_tree(True, certified=True); H.scenes.build_bunny(cb, W, Hh)
+    cctx = H.jp.Context(0)
+    try:
+        cctx.upload(cb.flatten())
+        assert cctx.build_info().certified_walk == 1
+        cfilm = cctx.render(p0)
+    finally:
+        cctx.close()
+    ndiff = int((~(cfilm[rows] == ref[rows]).all(-1)).sum())
+    print("configs[4] shard 0/8, certified walk vs verbatim walk: %d of %d pixels differ" % (ndiff, int(rows.sum()) * W))
+    assert ndiff <= 3 and (cfilm[~rows] == 0).all()
     # shard union at 2 spp: what the RCCL reduce(sum) assembles (disjoint bands, zero elsewhere) equals the one-GPU film
     low = 2
     whole = gpu_ctx.render(H.jp.render_params(W, Hh, low, band_rows=band))
