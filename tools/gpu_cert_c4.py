@@ -20,7 +20,8 @@ def film(certified, env):
         for k in env: os.environ.pop(k, None)
     return f, c, bi
 ref, rc, _ = film(False, {})
-for env in ({}, {"JETPBRT_CERT_EYE": "0.05"}, {"JETPBRT_CERT_SLACK": "16384"}, {"JETPBRT_CERT_EYE": "0.05", "JETPBRT_CERT_SLACK": "16384"}):
+variants = [dict(x.split("=") for x in v.split()) if v.strip() else {} for v in sys.argv[2:]] or [{}, {"JETPBRT_CERT_EYE": "0.05"}, {"JETPBRT_CERT_SLACK": "1024"}, {"JETPBRT_CERT_SLACK": "1024", "JETPBRT_CERT_EYE": "0.05"}]
+for env in variants:
     f, c, bi = film(True, env)
     bad = np.argwhere(~(f == ref).all(-1))
     print("%-50s differing pixels %d %s | rays %d/%d vs %d/%d | edge-on leaves %d, walked again %d" % (" ".join("%s=%s" % kv for kv in env.items()) or "(default)", len(bad),
