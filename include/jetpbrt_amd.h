@@ -111,7 +111,8 @@ typedef struct JpScene {
      *    walked again as in (1).  About twice as fast as (1).  One class of rays is outside the proof: a ray within fp32 noise of a
      *    triangle's plane is accepted or not by the signs of rounding errors, wherever along the ray that triangle lies.  Rays from the camera
      *    position are covered (leaves with a primitive edge-on to the camera are never culled by distance for them); for secondary rays there is
-     *    only the measurement: the 280k-triangle frame at 800x600x2048 is bit-identical to (1) (DESIGN.md "Certified walk").  Smaller scenes: as (1). */
+     *    only a generous distance-cull slack and the measurement: the 280k-triangle frame at 800x600x2048 and a 1/8 shard of 1920x1080x4096 are bit-identical
+     *    to (1) (DESIGN.md "Certified walk").  Smaller scenes: as (1). */
     int32_t bvh_reference_semantics;
 
     /* FDisk (shape.h:189-275): position, normal (already normalised by the constructor, shape.h:194), radius */
