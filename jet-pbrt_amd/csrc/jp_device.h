@@ -70,7 +70,7 @@ struct SceneView
 	const uint4* wide; int n_wide;          // large scenes: 8-wide quantised nodes, 5 x 16 bytes each (traverse_wide)
 	const float4* cut; int n_cut;           // other than tiny scenes: boxes of the <= 16 largest subtrees below the root in the flat_boxes layout (one bit each): the sort key of k_extend_sort / k_shadow_sort
 	const uint4* q4; int n_q4;              // large scenes: 4-wide tree with quantised child boxes, 4 x 16 bytes per node (Walker<4>)
-	const float4* refbox; float cert_pad;   // reference semantics, certified walk (Walker<6>): per device primitive the exact box of its leaf in the caller's tree (min, max); distance-cull slack c in tmax + c * tmax^2
+	const float4* refbox; float cert_pad, cert_pad_eye;   // (cert_pad_eye: the slack for rays from the camera position, which the edge-on flags cover)  // reference semantics, certified walk (Walker<6>): per device primitive the exact box of its leaf in the caller's tree (min, max); distance-cull slack c in tmax + c * tmax^2
 };
 
 // ---- shape intersection: exact restatements ---------------------------------------------------------------------
@@ -643,7 +643,7 @@ template <bool kCert> struct WalkerQ4
 			const unsigned int ayn = ny ? q2.y : q3.x, ayf = ny ? q3.x : q2.y;
 			const unsigned int azn = nz ? q2.z : q3.y, azf = nz ? q3.y : q2.z;
 			float tn[4]; bool hc[4]; int nh = 0;
-			const float tcull = kCert ? fmaf(sc.cert_pad * tmax, tmax, tmax) : tmax;
+			const float tcull = kCert ? fmaf((from_eye ? sc.cert_pad_eye : sc.cert_pad) * tmax, tmax, tmax) : tmax;
 			const float tcull_eye = (kCert && from_eye) ? JP_INF : tcull;                  // for the children with the edge-on flag (bits 0..3 of q3.z)
 			#pragma unroll
 			for (int i = 0; i < 4; i++)

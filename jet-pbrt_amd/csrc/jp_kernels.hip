@@ -2062,7 +2062,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	bool want_cert = s->bvh_reference_semantics == 2;
 	if (const char* e = getenv("JETPBRT_CERTIFIED")) want_cert = atoi(e) != 0;                // (experiments: either way round)
 	bool use_cert = want_cert && ref_sem && s->n_primitives > 1024 && cert_item_first.size() >= 64;
-	std::vector<float4> refbox; float cert_pad = 0.f;
+	std::vector<float4> refbox; float cert_pad = 0.f, cert_pad_eye = 0.f;
 	if (use_cert)
 	{
 		const int ni = (int)cert_item_first.size();
@@ -2114,6 +2114,9 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 			// diagonal) * tmax^2.  K = 1024: 3 of 259,200 pixels of the configs[4] shard (3.1e9 rays) off; 16384: none, for 4 % of the frame rate (profiles/r03l_certified_walk.txt)
 			float K = 16384.f; if (const char* e = getenv("JETPBRT_CERT_SLACK")) K = std::max(0.f, (float)atof(e));
 			cert_pad = (float)(K * 1.1920929e-7 / std::max(1e-20, diag / ni));
+			// rays from the camera position: their noise planes are covered by the edge-on flags, so the slack only has to cover the fringe in front of a leaf's box
+			float Ke = std::min(K, 1024.f); if (const char* e = getenv("JETPBRT_CERT_SLACK_EYE")) Ke = std::max(0.f, (float)atof(e));
+			cert_pad_eye = (float)(Ke * 1.1920929e-7 / std::max(1e-20, diag / ni));
 		}
 	}
 
@@ -2316,7 +2319,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	v.cut = (const float4*)c->d_cut; v.n_cut = (int)(cut.size() / 2);
 	v.wide = (const uint4*)c->d_wide; v.n_wide = dev_wide ? dev_n_wide : (int)(wide.size() / 20);
 	v.q4 = (const uint4*)c->d_q4; v.n_q4 = dev_q4 ? dev_n_q4 : (int)(q4.size() / 16);
-	v.refbox = (const float4*)c->d_refbox; v.cert_pad = cert_pad; c->cert = use_cert;
+	v.refbox = (const float4*)c->d_refbox; v.cert_pad = cert_pad; v.cert_pad_eye = cert_pad_eye; c->cert = use_cert;
 	c->dual = false; if (const char* e = getenv("JETPBRT_DUAL")) c->dual = atoi(e) != 0;
 	c->trav_lds_pad = 0; if (const char* e = getenv("JETPBRT_TRAV_LDS_PAD")) { const long v = atol(e); if (v > 0 && v <= 48 * 1024) c->trav_lds_pad = (size_t)v & ~(size_t)15; }
 	c->use_q4 = use_q4; c->q4_shadow = use_q4;                       // shadow rays too (measured against the 8-wide tree: k_shadow 53.8 -> 52.7 ms per 512 spp, frame +4 %)
