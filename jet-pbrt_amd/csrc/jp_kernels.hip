@@ -1698,6 +1698,8 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 	if (s->n_primitives <= 0) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: scene has no primitives");
 	if (s->n_triangles < 0 || s->n_rectangles < 0 || s->n_spheres < 0 || s->n_disks < 0 || s->n_materials < 0 || s->n_lights < 0 || s->n_bvh_nodes < 0 || s->n_bvh_prim_indices < 0)
 		return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: negative count");
+	if (s->bvh_reference_semantics < 0 || s->bvh_reference_semantics > 2) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: bvh_reference_semantics must be 0, 1 or 2");
+	if (s->bvh_reference_semantics != 0 && s->n_bvh_nodes == 0) return fail(JP_ERR_INVALID_ARGUMENT, "jp_upload_scene: reference semantics need the caller's tree (n_bvh_nodes == 0)");
 	const bool device_build = s->n_bvh_nodes == 0;              // no hierarchy handed over: build it on the device (jp_lbvh.h)
 	const bool ref_sem = !device_build && (s->bvh_reference_semantics == 1 || s->bvh_reference_semantics == 2);   // walk the caller's tree with the reference's semantics (traverse_ref)
 	if (!s->prim_shape_type || !s->prim_shape_index || !s->prim_material || !s->prim_light || (!device_build && (!s->bvh_bounds || !s->bvh_left || !s->bvh_right || !s->bvh_prim_index)))

@@ -234,6 +234,14 @@ def test_error_behaviour(H):
         with pytest.raises(jp.JetPbrtError) as e:
             ctx.upload(C.pointer(bad2))
         assert "BVH" in str(e.value)
+        bad3 = jp.JpScene.from_buffer_copy(s); bad3.bvh_reference_semantics = 3
+        with pytest.raises(jp.JetPbrtError) as e:
+            ctx.upload(C.pointer(bad3))
+        assert "bvh_reference_semantics" in str(e.value)
+        bad4 = jp.JpScene.from_buffer_copy(s); bad4.bvh_reference_semantics = 2; bad4.n_bvh_nodes = 0      # the certified walk is a walk of the CALLER's tree
+        with pytest.raises(jp.JetPbrtError) as e:
+            ctx.upload(C.pointer(bad4))
+        assert "caller's tree" in str(e.value)
         ctx.upload(sp)                                                       # still usable afterwards
         assert ctx.render(jp.render_params(8, 8, 1)).mean() > 0
     finally:
