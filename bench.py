@@ -10,14 +10,18 @@ already resident in HBM, film download included.  The HEA
 configs[2] -- the reference's own Cornell scene (main.cc:27-33: metal tall box) at 512x512, 1024 spp -- timed over EXACTLY
 --steps frames after --warmup untimed ones.  At N = 1 the line also carries a `configs` object with one full sub-record per
 single-GPU configuration of BASELINE.json (configs[1] Lambertian-only Cornell, configs[2] full materials, configs[3] the
-bunny scene of main.cc:64-111 at 800x600, 2048 spp): each is timed over its own region of >= --min-seconds (default 10 s);
+bunny scene of main.cc:64-111 at 800x600, 2048 spp) and -- round 4 -- configs[4]'s frame (1920x1080, 4096 spp) rendered WHOLE on the
+one GPU: the N = 1 figure an 8-GPU run of that frame divides by; each is timed over its own region of >= --min-seconds (default 10 s);
 their figures are summarised in `config.sub` of the one stdout line, the full sub-records (roofline, cpu_baseline,
 l2_vs_cpu_ref) are written to stderr as one `configs_detail {...}` line.
 
 At N > 1 the row bands of the film (the reference's FRenderTask unit, integrator.cc:53: 20 rows; here the largest height
 <= 20 that deals evenly) are dealt round-robin to the ranks, each rank renders its bands into a device film that is zero
-elsewhere, and ONE RCCL reduce(sum) over xGMI assembles the film on rank 0.  --scaling weak (default): the sample count
+elsewhere, and ONE RCCL gather of the ranks' packed rows over xGMI assembles the film on rank 0.  --scaling weak (default): the sample count
 grows with N (spp = --spp * N), every GPU traces as many paths as in the 1-GPU run; --scaling strong: the frame is fixed.
+An N > 1 run checks itself (`shard_check` in the line; the run FAILS otherwise): the process group has exactly --gpus ranks, every
+rank reports the samples of its own bands (one all_gather of the per-rank counters) and they add up to the frame, and every rank's bands arrived
+in the assembled film (no rank's rows are all zero).
 
 Rank 0 prints one JSON line.  Besides the contract fields:
   roofline     : dominant kernel class, algorithmic bytes per launch / HIP-event launch duration (events on the kernel
@@ -166,7 +170,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel (weak scaling: per GPU share, total spp = spp * gpus)")
     ap.add_argument("--full-materials", action="store_true", help="kept for round-1 command lines: same as --scene cornell")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--configs", default="1,2,3", help="sub-records at N = 1: comma list of BASELINE.json config indices, '' for none")
+    ap.add_argument("--configs", default="1,2,3,4", help="sub-records at N = 1: comma list of BASELINE.json config indices, '' for none")
     ap.add_argument("--min-seconds", type=float, default=10.0, help="length of each sub-record's timed region")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity samples")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-lane step behind roofline.alone (profiling runs: keeps rocprofv3's per-kernel averages to the timed configuration)")
@@ -215,7 +219,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_workload(scene_key, W, H, spp, steps, warmup, min_seconds=None, with_cpu=True, tag=""):
+    def run_workload(scene_key, W, H, spp, steps, warmup, min_seconds=None, with_cpu=True, tag="", parity_fn=None):
         """upload, warm up, time `steps` frames (or as many as fill min_seconds), profile the last one; returns the record"""
         spp_total = spp * n if args.scaling == "weak" else spp
         be = build_scene(scenes, scenes.HostBackend("bench"), scene_key, W, H)
@@ -260,6 +264,27 @@ def main():
         samples_per_step = W * H * spp_total
         value = samples_per_step * steps / dt / 1e6
         c = ctx.counters()                                     # counters + per-class event times of the last timed step
+        shard_check = None
+        if dist is not None:
+            # the N > 1 run checks itself: exactly N ranks took part, each traced the samples of its own bands, together the whole
+            # frame, and the assembled film has no empty row (a rank whose rows never arrived would leave its bands zero)
+            mine = torch.tensor([int(c.samples)], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            per = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(per, mine)
+            per = [int(t.item()) for t in per]
+            expect = [sum(y1 - y0 for y0, y1 in jp.distributed.bands_of(H, r, world, band_rows)) * W * spp_total for r in range(world)]
+            shard_check = {"world_size": dist.get_world_size(), "ranks_expected": n, "samples_per_rank": per, "samples_expected_per_rank": expect,
+                           "samples_total": sum(per), "samples_frame": samples_per_step}
+            ok = dist.get_world_size() == n and per == expect and sum(per) == samples_per_step
+            if rank == 0:
+                # (a black row is legitimate -- the Cornell camera looks past the box; a rank whose rows never arrived leaves ALL its bands zero)
+                rows_filled = np.abs(film.reshape(H, -1)).max(axis=1) > 0
+                empty = [r for r in range(world) if not any(rows_filled[y0:y1].any() for y0, y1 in jp.distributed.bands_of(H, r, world, band_rows))]
+                shard_check["ranks_with_empty_bands"] = empty; shard_check["empty_rows"] = int((~rows_filled).sum()); shard_check["finite"] = bool(np.isfinite(film).all())
+                ok = ok and not empty and shard_check["finite"]
+            shard_check["ok"] = bool(ok)
+            if not ok:
+                raise SystemExit("bench.py: the %d-rank frame is incomplete: %s" % (n, json.dumps(shard_check)))
         bi = ctx.build_info()
         lanes = int(bi.lanes_last_render)
         # With several lanes a launch shares the GPU with the other lanes' kernels, so its duration (and the per-launch roofline
@@ -282,7 +307,11 @@ def main():
                        SCENE_LABEL[scene_key], W, H, spp_total, (" (%d per GPU share)" % spp) if (n > 1 and args.scaling == "weak") else ""),
                    "traversal_mode": int(bi.traversal_mode), "lanes": lanes,
                    "roofline": roofline_record(c, c1, value, spp_total, n, lanes, scene_key, prof)}
-            if with_cpu and Hn is not None and (n == 1 or os.environ.get("JETPBRT_BENCH_PARITY_ALL")):
+            if shard_check is not None:
+                rec["shard_check"] = shard_check
+            if parity_fn is not None and n == 1 and not args.no_cpu:
+                rec["cpu_baseline"], rec["l2_vs_cpu_ref"] = parity_fn(scene_key, scene, film, W, H, spp_total)
+            elif with_cpu and Hn is not None and (n == 1 or os.environ.get("JETPBRT_BENCH_PARITY_ALL")):
                 rec["cpu_baseline"], rec["l2_vs_cpu_ref"] = cpu_and_parity(scene_key, scene, film, W, H, spp_total)
             else:
                 rec["cpu_baseline"], rec["l2_vs_cpu_ref"] = None, None
@@ -340,6 +369,18 @@ def main():
                     lrows[y0:y1] = True
                 link = bool(np.array_equal(gband[lrows].view(np.uint32), oband[lrows].view(np.uint32)))
                 link_l2 = float(np.sqrt(((gband[lrows] - oband[lrows]) ** 2).sum(-1)).mean())
+                # ... and at the FULL sample count (round 4): twelve single rows across the image (rows j % 50 == 37: twelve oracle tasks) of the
+                # full-size reference-tree film itself against the CPU oracle -- every sample index of the frame, strictly compared
+                pf_rows = jp.render_params(W, H, spp_total, 5, 1234, band_rows=1, shard_index=37, shard_count=50)
+                Hn.libc_srand(1)
+                t1 = time.perf_counter()
+                ofull, _ = Hn.oracle_render(rscene, pf_rows, tb)
+                t_full = time.perf_counter() - t1
+                frows = np.zeros(H, bool)
+                for y0, y1 in jp.distributed.bands_of(H, 37, 50, 1):
+                    frows[y0:y1] = True
+                link_full = bool(np.array_equal(ref[frows].view(np.uint32), ofull[frows].view(np.uint32)))
+                link_full_l2 = float(np.sqrt(((ref[frows] - ofull[frows]) ** 2).sum(-1)).mean())
             finally:
                 rctx.close()
             # the certified walk over the same (reference) tree -- FScene::certifiedWalk, DESIGN.md "Certified walk": speed, and how far its film is from the verbatim one
@@ -365,7 +406,9 @@ def main():
             parity = {"mean_per_pixel_l2": float(d.mean()), "max_per_pixel_l2": float(d.max()), "pixels": int(d.size), "spp": spp_total,
                       "tolerance": 1e-4,
                       "reference": "device reference-tree mode (traversal mode 5: the reference's rand()-driven tree, its box test and order) at the full size, %.1f s" % t_ref_gpu,
-                      "reference_vs_oracle": {"sample": "%d rows spread over the image (2-row bands j %% 30 == 8) at %d spp, oracle/pt_oracle.cc on the CPU, %.1f s" % (int(lrows.sum()), low, t_link), "bit_identical": link, "mean_per_pixel_l2": link_l2},
+                      "reference_vs_oracle": {"sample": "%d rows spread over the image (2-row bands j %% 30 == 8) at %d spp, oracle/pt_oracle.cc on the CPU, %.1f s" % (int(lrows.sum()), low, t_link), "bit_identical": link, "mean_per_pixel_l2": link_l2,
+                                              "full_spp": {"sample": "%d single rows (j %% 50 == 37) at the full %d spp = %d samples, %.1f s on %d threads" % (int(frows.sum()), spp_total, int(frows.sum()) * W * spp_total, t_full, tb),
+                                                           "bit_identical": link_full, "mean_per_pixel_l2": link_full_l2}},
                       "fraction_pixels_identical": float((film == ref).all(-1).mean()), "fraction_pixels_gt_1e-3": float((d > 1e-3).mean()),
                       "band_through_meshes": {"band": b, "mean_per_pixel_l2": float(band.mean()), "fraction_pixels_identical": float((film[b * 20:b * 20 + 20] == ref[b * 20:b * 20 + 20]).all(-1).mean())},
                       "note": "the default path walks its own SAH tree: ~3e-4 of the samples through the meshes find a different first hit than the reference's rand()-driven tree does (fringe hits, DESIGN.md Numerics)",
@@ -398,6 +441,33 @@ def main():
             cpu["at_min_cores_bands"] = {"value": round(nsamp / t_pb / 1e6, 3), "cores": tb, "kind": "port"}
         return cpu, parity
 
+    def parity_config4(scene_key, scene, film, W, H, spp_total):
+        """configs[4] on ONE GPU: the rows rank 0 of 8 would own (15-row bands b % 8 == 0), default path vs the device's reference-tree
+        mode at the full 4096 spp (the pairing of tests/test_gpu_parity.py::test_config4_...; the CPU reference of this scene is timed in
+        the configs[3] record -- its rate does not depend on the frame size)"""
+        worldc = 8
+        band = jp.distributed.balanced_band_rows(H, worldc)
+        rows = np.zeros(H, bool)
+        for y0, y1 in jp.distributed.bands_of(H, 0, worldc, band):
+            rows[y0:y1] = True
+        rb = scenes.HostBackend("bench_ref4")
+        rb.set_reference_tree(True)
+        build_scene(scenes, rb, scene_key, W, H)
+        rctx = jp.Context(dev)
+        try:
+            rctx.upload(rb.flatten())
+            t1 = time.perf_counter()
+            ref = rctx.render(jp.render_params(W, H, spp_total, 5, 1234, band_rows=band, shard_index=0, shard_count=worldc))
+            t_ref = time.perf_counter() - t1
+        finally:
+            rctx.close()
+        d = np.sqrt(((film[rows] - ref[rows]) ** 2).sum(-1))
+        parity = {"mean_per_pixel_l2": float(d.mean()), "max_per_pixel_l2": float(d.max()), "pixels": int(d.size), "spp": spp_total, "tolerance": 1e-4,
+                  "reference": "device reference-tree mode (traversal mode 5) on the rows of rank 0 of 8 (%d-row bands b %% 8 == 0: %d rows), %.1f s; linked to the CPU oracle in the configs[3] record" % (band, int(rows.sum()), t_ref),
+                  "fraction_pixels_identical": float((film[rows] == ref[rows]).all(-1).mean()), "fraction_pixels_gt_1e-3": float((d > 1e-3).mean()),
+                  "outside_shard_zero": bool((ref[~rows] == 0).all())}
+        return None, parity
+
     # ---- headline ----------------------------------------------------------------------------------------------------------
     hk, hw, hh, hspp = CONFIGS[args.config]
     if args.full_materials:
@@ -406,16 +476,16 @@ def main():
         hk = args.scene
     hw = args.width or hw; hh = args.height or hh; hspp = args.spp or hspp
     sub_ids = [int(x) for x in args.configs.split(",") if x.strip()] if (n == 1 and args.configs) else []
-    sub_ids = [i for i in sub_ids if i in (1, 2, 3)]
+    sub_ids = [i for i in sub_ids if i in (1, 2, 3, 4)]
     custom = bool(args.scene or args.width or args.height or args.spp or args.full_materials or args.config != 2)
     if custom:
-        sub_ids = [] if args.configs == "1,2,3" else sub_ids          # a custom headline runs alone unless sub-records are asked for
+        sub_ids = [] if args.configs == "1,2,3,4" else sub_ids          # a custom headline runs alone unless sub-records are asked for
     head_in_sub = (not custom) and 2 in sub_ids
     head, band_rows, lanes = run_workload(hk, hw, hh, hspp, args.steps, args.warmup, with_cpu=not head_in_sub)
     subs = {}
     for i in sub_ids:
         k, w, h, s = CONFIGS[i]
-        rec, _, _ = run_workload(k, w, h, s, 0, 1, min_seconds=args.min_seconds)
+        rec, _, _ = run_workload(k, w, h, s, 0, 1, min_seconds=args.min_seconds, parity_fn=(parity_config4 if i == 4 else None))
         if rank == 0:
             subs["configs[%d]" % i] = rec
     if rank == 0:
@@ -431,6 +501,8 @@ def main():
             "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"], "l2_vs_cpu_ref": head["l2_vs_cpu_ref"],
             "timed_region_s": head["timed_region_s"],
         }
+        if head.get("shard_check") is not None:
+            out["shard_check"] = head["shard_check"]
         if subs:
             out["config"]["sub"] = {k.replace("configs[", "c").replace("]", ""): {
                 "Msamples_s": v["value"], "ms": v["ms_per_step"], "frames": v["steps"], "s": v["timed_region_s"], "whole_path_frac": v["roofline"]["whole_path"]["frac"],

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define JP_ABI_VERSION 6
+#define JP_ABI_VERSION 7
 
 typedef enum JpStatus {
     JP_OK = 0,
@@ -176,6 +176,47 @@ typedef struct JpBuildInfo {
                                     camera rays are not culled by distance there (DESIGN.md "Certified walk") */
 } JpBuildInfo;
 
+
+/* ABI 7: everything a host application may want to steer, by value (round 3 read 42 JETPBRT_* environment variables at upload / render time).
+ * Set with jp_set_options BEFORE the jp_upload_scene / jp_render* calls it is to affect; fields left 0 keep the library's defaults (tri-state
+ * switches: 0 default, 1 on, -1 off).  The environment is read ONCE, in jp_create_context, as the initial value of this struct (JETPBRT_<FIELD> in
+ * capitals; "0" means off): a test override, not an interface.  jp_get_options returns the values in force. */
+typedef struct JpOptions {
+    int32_t struct_bytes;        /* sizeof(JpOptions) of the caller (a longer struct of a later ABI is truncated, a shorter one zero-extended) */
+    /* ---- schedule (jp_render*) ---- */
+    int32_t lanes;               /* stream lanes per GPU, 1-4 (0: by frame size -- three for the benchmark frames; DESIGN.md "Stream lanes")  */
+    int32_t lane_rows;           /* rows per lane group (0: 4)                                                                                 */
+    int32_t blocks_per_cu;       /* workgroups (= queue regions) per CU and launch (0: 16; 5 per lane with three lanes)                        */
+    int64_t max_slots;           /* cap on the path slots of one batch (0: from free device memory, <= 2^26)                                   */
+    int32_t compact_regions;     /* k_raygen: a region = consecutive (pixel block, sample) chunks (default for scenes walked through HBM)      */
+    int32_t fused;               /* 1: the single-launch schedule k_path (DESIGN.md "One schedule"; measured slower, kept for its 1.2 GB of queues) */
+    int32_t fused_region, fused_job_spp, fused_workgroups;   /* its region size / samples per job / resident workgroups per CU (0: defaults)  */
+    /* ---- traversal (jp_upload_scene) ---- */
+    int32_t traversal;           /* force a traversal mode for a host-built tree: 1 + mode (1: binary tree in HBM, 2: binary tree in LDS, 3: flat leaf list, 4: + 8-wide shadow tree); 0: by scene size */
+    int32_t q4;                  /* closest-hit rays of large scenes through the 4-wide quantised tree (default on)                            */
+    int32_t q4_shadow;           /* ... and their shadow rays (default on; off: the 8-wide tree)                                               */
+    int32_t persist;             /* lane refill in the traversal kernels of large scenes: idle lanes that trigger a refill, 8 / 16 / 32 (0: 16; -1: one ray per lane) */
+    int32_t vote;                /* per-iteration node / leaf vote of the refill kernels (default on, off for the verbatim reference walk)    */
+    int32_t stack_lds_words;     /* traversal-stack words per thread kept in LDS, the rest spills to HBM (0: 12)                               */
+    int32_t shade_sort;          /* k_shade partitions its region by material class (default: scenes with more than one material kind)         */
+    int32_t device_tree;         /* hierarchy built on the device: 1 PLOC clustering (default), 2 LBVH (Karras) topology                       */
+    int32_t device_wide;         /* device build: also the 8-wide shadow tree (default on)                                                     */
+    int32_t bvh_max_leaf;        /* device build: primitives per leaf (0: 2 for PLOC, 3 for LBVH)                                              */
+    int32_t ploc_radius, ploc_max_rounds;   /* PLOC neighbour search radius (0: 16) and round limit (0: 512; beyond it the LBVH topology serves) */
+    /* ---- reference semantics, certified walk (JpScene.bvh_reference_semantics = 2; DESIGN.md "Certified walk") ---- */
+    int32_t certified;           /* -1: walk every ray verbatim even when the scene asks for the certified walk (it never turns the certified walk ON for a scene that asked for the verbatim one) */
+    float   cert_slack;          /* K of the distance-cull slack tmax + K eps / (mean leaf diagonal) tmax^2 for rays not from the camera (0: 16384; < 0: none) */
+    float   cert_slack_eye;      /* the same for rays from the camera position (0: 1024; < 0: none)                                            */
+    float   cert_eye_tau;        /* a leaf is "edge-on to the camera" when |n.(p - eye)| <= tau |p - eye| (0: 5e-3; < 0: no flags)             */
+    /* ---- host libm the device reproduces (0: probe the running libm in jp_create_context) ---- */
+    int32_t libm_sincosf;        /* 1 / 2: glibc's FMA / plain build; -1: none (own correctly rounded evaluation)                              */
+    int32_t libm_xbsdf;          /* bit 0 exact, bit 1 FMA build; -1: none                                                                     */
+    /* ---- diagnostics (tests, tools/) ---- */
+    int32_t trace_walk;          /* jp_trace on a large scene walks: 0 what the render's closest-hit rays walk, 1 the binary tree, 2 the 8-wide tree, 3 the caller's tree verbatim */
+    float   box_pad;             /* every box of a host-built tree grows by this many scene units (fringe census, tools/gpu_fringe_census.py)  */
+    int32_t reserved[8];
+} JpOptions;
+
 typedef struct JpContext JpContext;
 
 const char* jp_last_error(void);
@@ -189,6 +230,9 @@ int  jp_probe_libm_xbsdf(void);
 /* one context per process per GPU (device_id = LOCAL_RANK) */
 int  jp_create_context(int device_id, JpContext** out);
 int  jp_destroy_context(JpContext* ctx);
+/* ABI 7: options by value (see JpOptions); jp_set_options(ctx, NULL) restores the defaults of jp_create_context (environment overrides included) */
+int  jp_set_options(JpContext* ctx, const JpOptions* options);
+int  jp_get_options(JpContext* ctx, JpOptions* out);
 
 /* validates every index in `scene` on the host, then copies it into device-resident SoA tables */
 int  jp_upload_scene(JpContext* ctx, const JpScene* scene);

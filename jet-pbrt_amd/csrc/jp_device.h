@@ -606,8 +606,13 @@ template <> struct Walker<3>
 // diagnostic builds only (tools/walk_stats.py): node steps, leaf steps, primitive tests, stack pushes of the 4-wide walks -- [0..3] closest-hit rays, [4..7] shadow rays
 __device__ unsigned long long g_walk_stats[8];
 #define JP_WS(i, v) atomicAdd(&g_walk_stats[(kAnyHit ? 4 : 0) + (i)], (unsigned long long)(v))
+// per wave iteration of the refill kernels, [0..15] closest-hit, [16..31] shadow: 0 node turns, 1 lanes stepping in them, 2 live lanes at node turns, 3 leaf turns,
+// 4 lanes stepping, 5 live lanes, 6 refill iterations, 7 lanes refilled, 8 turns with the pool empty (drain), 9 live lanes in those, 10 lanes stepping in those
+__device__ unsigned long long g_turn_stats[32];
+#define JP_TURN(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_turn_stats[(kAnyHit ? 16 : 0) + (i)], (unsigned long long)(v)); } while (0)
 #else
 #define JP_WS(i, v) do { } while (0)
+#define JP_TURN(i, v) do { } while (0)
 #endif
 template <bool kCert> struct WalkerQ4
 {
@@ -623,103 +628,112 @@ template <bool kCert> struct WalkerQ4
 	{ const float4 b0 = sc.refbox[2 * (size_t)p], b1 = sc.refbox[2 * (size_t)p + 1]; return ref_box_exact(b0, b1, o, d, tmin, t); }
 	// closest hit: is (tmax, hit) what the reference returns?  (any-hit rays are decided as they go: hit >= 0 is certain, unsure says the rest)
 	__device__ __forceinline__ bool certain(const SceneView& sc) const { return !unsure && (hit < 0 || leaf_box_passes(sc, hit, tmax)); }
-	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, const WalkStack& stack)
+	__device__ __forceinline__ void pop(const WalkStack& stack) { if (sp > 0) { sp--; cur = stack.get(sp); } else done = true; }
+	// one interior node: the four quantised child boxes, the hit ones in exact near-to-far order
+	template <bool kAnyHit> __device__ __forceinline__ void node_step(const SceneView& sc, const WalkStack& stack)
 	{
-		bool pop = true;
-		if (cur >= 0)
+		const uint4* __restrict__ nd = sc.q4 + 4 * (size_t)cur;
+		const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2]; const uint2 q3 = *(const uint2*)(nd + 3);
+		const unsigned int eyebits = kCert ? ((const unsigned int*)(nd + 3))[2] : 0u;
+		// slab distance of plane byte q on axis x: ((p.x + q * 2^e.x) - o.x) / d.x = q * A.x + B.x with A = 2^e / d, B = (p - o) / d: one
+		// conversion and one fma per plane.  Rounding: |error| <~ 3e-7 * (node extent) / |d| -- covered by the host's padding of every child
+		// box by 1e-6 of the node's extent before it is quantised outward (jp_upload_scene), on top of the 2e-6 relative slack below.
+		const float ax = __uint_as_float((q0.w & 0xffu) << 23) * ix, ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * iy, az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * iz;
+		const float bx = (__uint_as_float(q0.x) - o.x) * ix, by = (__uint_as_float(q0.y) - o.y) * iy, bz = (__uint_as_float(q0.z) - o.z) * iz;
+		// near / far plane of each axis by the sign of the direction: min / max of the two slab distances without computing both orders
+		// (a NaN -- 0 * inf on an axis the ray is parallel to -- is dropped by fmaxf / fminf: that axis then does not constrain, conservative)
+		const bool nx = ix >= 0.f, ny = iy >= 0.f, nz = iz >= 0.f;
+		const unsigned int axn = nx ? q2.x : q2.w, axf = nx ? q2.w : q2.x;
+		const unsigned int ayn = ny ? q2.y : q3.x, ayf = ny ? q3.x : q2.y;
+		const unsigned int azn = nz ? q2.z : q3.y, azf = nz ? q3.y : q2.z;
+		float tn[4]; bool hc[4]; int nh = 0;
+		const float tcull = kCert ? fmaf((from_eye ? sc.cert_pad_eye : sc.cert_pad) * tmax, tmax, tmax) : tmax;
+		const float tcull_eye = (kCert && from_eye) ? JP_INF : tcull;                  // for the children with the edge-on flag (bits 0..3 of q3.z)
+		#pragma unroll
+		for (int i = 0; i < 4; i++)
 		{
-			const uint4* __restrict__ nd = sc.q4 + 4 * (size_t)cur;
-			const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2]; const uint2 q3 = *(const uint2*)(nd + 3);
-			const unsigned int eyebits = kCert ? ((const unsigned int*)(nd + 3))[2] : 0u;
-			// slab distance of plane byte q on axis x: ((p.x + q * 2^e.x) - o.x) / d.x = q * A.x + B.x with A = 2^e / d, B = (p - o) / d: one
-			// conversion and one fma per plane.  Rounding: |error| <~ 3e-7 * (node extent) / |d| -- covered by the host's padding of every child
-			// box by 1e-6 of the node's extent before it is quantised outward (jp_upload_scene), on top of the 2e-6 relative slack below.
-			const float ax = __uint_as_float((q0.w & 0xffu) << 23) * ix, ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * iy, az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * iz;
-			const float bx = (__uint_as_float(q0.x) - o.x) * ix, by = (__uint_as_float(q0.y) - o.y) * iy, bz = (__uint_as_float(q0.z) - o.z) * iz;
-			// near / far plane of each axis by the sign of the direction: min / max of the two slab distances without computing both orders
-			// (a NaN -- 0 * inf on an axis the ray is parallel to -- is dropped by fmaxf / fminf: that axis then does not constrain, conservative)
-			const bool nx = ix >= 0.f, ny = iy >= 0.f, nz = iz >= 0.f;
-			const unsigned int axn = nx ? q2.x : q2.w, axf = nx ? q2.w : q2.x;
-			const unsigned int ayn = ny ? q2.y : q3.x, ayf = ny ? q3.x : q2.y;
-			const unsigned int azn = nz ? q2.z : q3.y, azf = nz ? q3.y : q2.z;
-			float tn[4]; bool hc[4]; int nh = 0;
-			const float tcull = kCert ? fmaf((from_eye ? sc.cert_pad_eye : sc.cert_pad) * tmax, tmax, tmax) : tmax;
-			const float tcull_eye = (kCert && from_eye) ? JP_INF : tcull;                  // for the children with the edge-on flag (bits 0..3 of q3.z)
+			const int sh = 8 * i;
+			const float x0 = fmaf((float)((axn >> sh) & 0xffu), ax, bx), x1 = fmaf((float)((axf >> sh) & 0xffu), ax, bx);
+			const float y0 = fmaf((float)((ayn >> sh) & 0xffu), ay, by), y1 = fmaf((float)((ayf >> sh) & 0xffu), ay, by);
+			const float z0 = fmaf((float)((azn >> sh) & 0xffu), az, bz), z1 = fmaf((float)((azf >> sh) & 0xffu), az, bz);
+			const float t0 = fmaxf(fmaxf(x0, y0), fmaxf(z0, tmin));
+			const float tf = fminf(fminf(x1, y1), fminf(z1, (kCert && ((eyebits >> i) & 1u)) ? tcull_eye : tcull));
+			hc[i] = ((q0.w >> (24 + i)) & 1u) && t0 <= tf * 1.000002f;
+			tn[i] = hc[i] ? fminf(t0, 3.0e38f) : JP_INF;             // a missed child ranks behind every hit one
+			nh += hc[i] ? 1 : 0;
+		}
+		const int ref[4] = { (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w };
+		// rank of a child = number of children entered before it (ties by child number: a total order; six comparisons); the hit
+		// children have the ranks 0 .. nh-1.  Any-hit rays: the children's own order (rank among the hit ones).
+		int r[4] = { 0, 0, 0, 0 };
+		if (kAnyHit) { r[1] = hc[0] ? 1 : 0; r[2] = r[1] + (hc[1] ? 1 : 0); r[3] = r[2] + (hc[2] ? 1 : 0); }
+		else
+		{
+			#pragma unroll
+			for (int i = 0; i < 4; i++)
+				#pragma unroll
+				for (int j = i + 1; j < 4; j++) { const bool first = tn[i] <= tn[j]; r[j] += first ? 1 : 0; r[i] += first ? 0 : 1; }
+		}
+		// rank 0 is walked next, the others go on the stack, farthest first.  No branch per child: while the three possible entries
+		// fit the LDS part of the stack, every child stores -- the ones with nothing to push into the word behind the stack's LDS part
+		// (the kernels allocate cap + 1 words per thread)
+		if (sp + 3 <= stack.cap)
+		{
 			#pragma unroll
 			for (int i = 0; i < 4; i++)
 			{
-				const int sh = 8 * i;
-				const float x0 = fmaf((float)((axn >> sh) & 0xffu), ax, bx), x1 = fmaf((float)((axf >> sh) & 0xffu), ax, bx);
-				const float y0 = fmaf((float)((ayn >> sh) & 0xffu), ay, by), y1 = fmaf((float)((ayf >> sh) & 0xffu), ay, by);
-				const float z0 = fmaf((float)((azn >> sh) & 0xffu), az, bz), z1 = fmaf((float)((azf >> sh) & 0xffu), az, bz);
-				const float t0 = fmaxf(fmaxf(x0, y0), fmaxf(z0, tmin));
-				const float tf = fminf(fminf(x1, y1), fminf(z1, (kCert && ((eyebits >> i) & 1u)) ? tcull_eye : tcull));
-				hc[i] = ((q0.w >> (24 + i)) & 1u) && t0 <= tf * 1.000002f;
-				tn[i] = hc[i] ? fminf(t0, 3.0e38f) : JP_INF;             // a missed child ranks behind every hit one
-				nh += hc[i] ? 1 : 0;
+				const bool push = hc[i] && r[i] != 0;
+				stack.lds[(push ? sp + nh - 1 - r[i] : stack.cap) * JP_BLOCK] = ref[i];
+				cur = (hc[i] && r[i] == 0) ? ref[i] : cur;
 			}
-			const int ref[4] = { (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w };
-			// rank of a child = number of children entered before it (ties by child number: a total order; six comparisons); the hit
-			// children have the ranks 0 .. nh-1.  Any-hit rays: the children's own order (rank among the hit ones).
-			int r[4] = { 0, 0, 0, 0 };
-			if (kAnyHit) { r[1] = hc[0] ? 1 : 0; r[2] = r[1] + (hc[1] ? 1 : 0); r[3] = r[2] + (hc[2] ? 1 : 0); }
-			else
-			{
-				#pragma unroll
-				for (int i = 0; i < 4; i++)
-					#pragma unroll
-					for (int j = i + 1; j < 4; j++) { const bool first = tn[i] <= tn[j]; r[j] += first ? 1 : 0; r[i] += first ? 0 : 1; }
-			}
-			// rank 0 is walked next, the others go on the stack, farthest first.  No branch per child: while the three possible entries
-			// fit the LDS part of the stack, every child stores -- the ones with nothing to push into the word behind the stack's LDS part
-			// (the kernels allocate cap + 1 words per thread)
-			if (sp + 3 <= stack.cap)
-			{
-				#pragma unroll
-				for (int i = 0; i < 4; i++)
-				{
-					const bool push = hc[i] && r[i] != 0;
-					stack.lds[(push ? sp + nh - 1 - r[i] : stack.cap) * JP_BLOCK] = ref[i];
-					cur = (hc[i] && r[i] == 0) ? ref[i] : cur;
-				}
-			}
-			else
-			{
-				#pragma unroll
-				for (int i = 0; i < 4; i++)
-					if (hc[i]) { if (r[i] == 0) cur = ref[i]; else stack.put(sp + nh - 1 - r[i], ref[i]); }
-			}
-			sp += nh > 0 ? nh - 1 : 0;
-			pop = nh == 0;
-			JP_WS(0, 1); JP_WS(3, nh > 0 ? nh - 1 : 0);
 		}
 		else
-		{   // one leaf per step (Walker<0>)
-			const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
-			JP_WS(1, 1); JP_WS(2, count);
-			if (kCert)
-			{
-				for (int k = 0; k < count; k++)
-				{
-					// accept distance <= tmax to see ties: prim_hit's `distance < bound` with the next float above tmax as the bound (inf stays inf)
-					float tm = __int_as_float(__float_as_int(tmax) + (tmax < JP_INF ? 1 : 0));
-					if (!prim_hit<4>(sc.prims, first + k, o, d, tmin, tm)) continue;
-					if (kAnyHit)
-					{
-						if (!(tm < tmax)) continue;                                       // distance == max_t: not a hit for the reference either
-						if (leaf_box_passes(sc, first + k, tm)) { hit = first + k; done = true; return; }
-						unsure = true;                                                    // accepted, but the reference may never reach this leaf: go on looking
-					}
-					else if (tm < tmax) { tmax = tm; hit = first + k; }
-					else if (hit >= 0) unsure = true;                                     // a second primitive at exactly the closest distance
-				}
-			}
-			else
-			for (int k = 0; k < count; k++)
-				if (prim_hit<4>(sc.prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) { done = true; return; } }
+		{
+			#pragma unroll
+			for (int i = 0; i < 4; i++)
+				if (hc[i]) { if (r[i] == 0) cur = ref[i]; else stack.put(sp + nh - 1 - r[i], ref[i]); }
 		}
-		if (pop) { if (sp > 0) { sp--; cur = stack.get(sp); } else done = true; }
+		sp += nh > 0 ? nh - 1 : 0;
+		JP_WS(0, 1); JP_WS(3, nh > 0 ? nh - 1 : 0);
+#ifdef JP_DBG_VALU_PAD
+		{   // diagnostic builds only: JP_DBG_VALU_PAD extra vector instructions per node step, same memory behaviour (profiles/r04a_walker_experiments.txt)
+			float pad = tmax;
+			#pragma unroll
+			for (int i = 0; i < JP_DBG_VALU_PAD; i++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(pad));
+			if (pad == 1.2345e-30f) hit = -3;
+		}
+#endif
+		if (nh == 0) pop(stack);
 	}
+	// one leaf: every primitive in order (Walker<0>: one leaf per step)
+	template <bool kAnyHit> __device__ __forceinline__ void leaf_step(const SceneView& sc, const WalkStack& stack)
+	{
+		const int e = -cur - 1, first = e >> 4, count = (e & 15) + 1;
+		JP_WS(1, 1); JP_WS(2, count);
+		if (kCert)
+		{
+			for (int k = 0; k < count; k++)
+			{
+				// accept distance <= tmax to see ties: prim_hit's `distance < bound` with the next float above tmax as the bound (inf stays inf)
+				float tm = __int_as_float(__float_as_int(tmax) + (tmax < JP_INF ? 1 : 0));
+				if (!prim_hit<4>(sc.prims, first + k, o, d, tmin, tm)) continue;
+				if (kAnyHit)
+				{
+					if (!(tm < tmax)) continue;                                       // distance == max_t: not a hit for the reference either
+					if (leaf_box_passes(sc, first + k, tm)) { hit = first + k; tmax = tm; done = true; return; }
+					unsure = true;                                                    // accepted, but the reference may never reach this leaf: go on looking
+				}
+				else if (tm < tmax) { tmax = tm; hit = first + k; }
+				else if (hit >= 0) unsure = true;                                     // a second primitive at exactly the closest distance
+			}
+		}
+		else
+		for (int k = 0; k < count; k++)
+			if (prim_hit<4>(sc.prims, first + k, o, d, tmin, tmax)) { hit = first + k; if (kAnyHit) { done = true; return; } }
+		pop(stack);
+	}
+	template <bool kAnyHit> __device__ __forceinline__ void step(const SceneView& sc, const WalkStack& stack)
+	{ if (cur >= 0) node_step<kAnyHit>(sc, stack); else leaf_step<kAnyHit>(sc, stack); }
 };
 template <> struct Walker<4> : WalkerQ4<false> {};
 template <> struct Walker<6> : WalkerQ4<true> {};

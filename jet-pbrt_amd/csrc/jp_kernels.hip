@@ -821,8 +821,21 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_sort(SceneView sc, Queues q
 //     deterministic -- and only those contributions are read from HBM.
 // LDS: [stack: stack_cap words per thread, deeper entries in the global spill array (WalkStack)][k_shadow_persist: bitmap of ceil(R * n_planes / 32) words]
 // ---------------------------------------------------------------------------------------------------------------------
+// One iteration of a refill kernel's wave: the lanes vote on the kind of step it runs (node / leaf) -- the one most active lanes wait for -- and the
+// minority sits it out.  (pool: rays are left in the region; only the diagnostic build's statistics use it, tools/turn_stats.py.)
+template <int kMode, bool kAnyHit, bool kVote>
+__device__ __forceinline__ void persist_turn(Walker<kMode>& w, const SceneView& sc, const WalkStack& stack, bool pool)
+{
+	const int nh = __popcll(__ballot(!w.done && w.heavy())), nl = __popcll(__ballot(!w.done && !w.heavy()));
+	const bool heavyTurn = kVote ? nh > nl : w.heavy();
+	if (kVote) { JP_TURN(heavyTurn ? 3 : 0, 1); JP_TURN(heavyTurn ? 4 : 1, heavyTurn ? nh : nl); JP_TURN(heavyTurn ? 5 : 2, nh + nl); if (!pool) { JP_TURN(8, 1); JP_TURN(9, nh + nl); JP_TURN(10, heavyTurn ? nh : nl); } }
+	if (!w.done && (w.heavy() == heavyTurn)) w.template step<kAnyHit>(sc, stack);
+}
+// rank of this lane among the set bits of a wave mask (bits below the lane): v_mbcnt, no 64-bit per-lane mask to keep alive
+__device__ __forceinline__ unsigned int lane_rank(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u)); }
+
 template <int kMode, int kRefill, bool kVote>
-__global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queues q, int cur_q, int stack_cap, int* spill, DevCounters* cnt)
+__global__ void __launch_bounds__(JP_BLOCK, 8) k_extend_persist(SceneView sc, Queues q, int cur_q, int stack_cap, int* spill, DevCounters* cnt)
 {
 	__shared__ unsigned int s_next;
 	const WalkStack stack = { (int*)s_dyn + threadIdx.x, spill + blockIdx.x * JP_BLOCK + threadIdx.x, (kMode == 4 || kMode == 6) ? stack_cap - 1 : stack_cap, gridDim.x * JP_BLOCK };   // Walker<4> / <6>: the last LDS word is the dump slot
@@ -831,7 +844,6 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queue
 	if (threadIdx.x == 0) s_next = 0;
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
-	const unsigned long long lt = (1ull << lane) - 1ull;
 	Walker<kMode> w; w.done = true; w.hit = -1; w.tmax = JP_INF;
 	unsigned int ridx = 0xffffffffu, h = 0;
 	bool pool = n > 0;                                               // wave-uniform: rays may be left in the region
@@ -852,10 +864,11 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queue
 			unsigned int start = 0;
 			if (lane == first) start = atomicAdd(&s_next, (unsigned int)nidle);
 			start = __shfl(start, first);
+			{ constexpr bool kAnyHit = false; (void)kAnyHit; JP_TURN(6, 1); JP_TURN(7, nidle); }
 			pool = start + (unsigned int)nidle < n;
 			if (w.done)
 			{
-				const unsigned int my = start + (unsigned int)__popcll(idle & lt);
+				const unsigned int my = start + lane_rank(idle);
 				if (my < n)
 				{
 					const float4 ro = q.ray_o[cur_q][rbase + my], rd = q.ray_d[cur_q][rbase + my];
@@ -867,11 +880,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queue
 			if (start >= n && nidle == 64) break;                    // the counter ran past the region while every lane was idle
 			continue;
 		}
-		{   // the lanes vote: this iteration runs the kind of step (node / leaf) most active lanes wait for; the others sit it out
-			const int nh = __popcll(__ballot(!w.done && w.heavy())), nl = __popcll(__ballot(!w.done && !w.heavy()));
-			const bool heavyTurn = kVote ? nh > nl : w.heavy();
-			if (!w.done && (w.heavy() == heavyTurn)) w.template step<false>(sc, stack);
-		}
+		persist_turn<kMode, false, kVote>(w, sc, stack, pool);
 	}
 	if constexpr (kMode == 6)
 	{   // the marked rays (a few in 10^4), FBVH_Node::Intersect's own walk
@@ -891,7 +900,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_extend_persist(SceneView sc, Queue
 }
 
 template <int kMode, int kRefill, bool kVote>
-__global__ void __launch_bounds__(JP_BLOCK) k_shadow_persist(SceneView sc, Queues q, RenderConst rc, int stack_cap, int* spill, DevCounters* cnt)
+__global__ void __launch_bounds__(JP_BLOCK, 8) k_shadow_persist(SceneView sc, Queues q, RenderConst rc, int stack_cap, int* spill, DevCounters* cnt)
 {
 	__shared__ unsigned int s_next;
 	const WalkStack stack = { (int*)s_dyn + threadIdx.x, spill + blockIdx.x * JP_BLOCK + threadIdx.x, (kMode == 4 || kMode == 6) ? stack_cap - 1 : stack_cap, gridDim.x * JP_BLOCK };   // Walker<4> / <6>: the last LDS word is the dump slot
@@ -903,7 +912,6 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shadow_persist(SceneView sc, Queue
 	if (threadIdx.x == 0) s_next = 0;
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
-	const unsigned long long lt = (1ull << lane) - 1ull;
 	Walker<kMode> w; w.done = true; w.hit = -1;
 	unsigned int rid = 0xffffffffu;
 	bool pool = total > 0;
@@ -924,10 +932,11 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shadow_persist(SceneView sc, Queue
 			unsigned int start = 0;
 			if (lane == first) start = atomicAdd(&s_next, (unsigned int)nidle);
 			start = __shfl(start, first);
+			{ constexpr bool kAnyHit = true; (void)kAnyHit; JP_TURN(6, 1); JP_TURN(7, nidle); }
 			pool = start + (unsigned int)nidle < total;
 			if (w.done)
 			{
-				const unsigned int my = start + (unsigned int)__popcll(idle & lt);
+				const unsigned int my = start + lane_rank(idle);
 				if (my < total)
 				{
 					const unsigned int k = my / E, e = my - k * E;
@@ -943,11 +952,7 @@ __global__ void __launch_bounds__(JP_BLOCK) k_shadow_persist(SceneView sc, Queue
 			if (start >= total && nidle == 64) break;
 			continue;
 		}
-		{
-			const int nh = __popcll(__ballot(!w.done && w.heavy())), nl = __popcll(__ballot(!w.done && !w.heavy()));
-			const bool heavyTurn = kVote ? nh > nl : w.heavy();
-			if (!w.done && (w.heavy() == heavyTurn)) w.template step<true>(sc, stack);
-		}
+		persist_turn<kMode, true, kVote>(w, sc, stack, pool);
 	}
 	__syncthreads();
 	if constexpr (kMode == 6)
@@ -3059,6 +3064,13 @@ extern "C" int jp_dbg_walk_stats(unsigned long long* out8)
 	unsigned long long z[8] = { 0 };
 	if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(jp::g_walk_stats), sizeof(z)) != hipSuccess) return -1;
 	if (hipMemcpyToSymbol(HIP_SYMBOL(jp::g_walk_stats), z, sizeof(z)) != hipSuccess) return -1;
+	return 0;
+}
+extern "C" int jp_dbg_turn_stats(unsigned long long* out32)
+{
+	unsigned long long z[32] = { 0 };
+	if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(jp::g_turn_stats), sizeof(z)) != hipSuccess) return -1;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(jp::g_turn_stats), z, sizeof(z)) != hipSuccess) return -1;
 	return 0;
 }
 #endif
