@@ -291,13 +291,13 @@ def main():
         # figure the contract asks for) reflects that sharing.  One extra, untimed step on ONE lane gives the same kernels' figures
         # when each has the GPU to itself -- reported next to the contract figure as roofline.alone.
         c1 = None
-        if lanes > 1 and "JETPBRT_LANES" not in os.environ and not args.no_exclusive:
-            os.environ["JETPBRT_LANES"] = "1"
+        if lanes > 1 and ctx.get_options().lanes == 0 and not args.no_exclusive:
+            ctx.set_options(lanes=1)                           # JpOptions (ABI 7): schedule fields apply to the next render
             try:
                 step()
                 c1 = ctx.counters()
             finally:
-                del os.environ["JETPBRT_LANES"]
+                ctx.set_options()
         ctx.set_profiling(False)
         rec = None
         if rank == 0:

@@ -68,6 +68,17 @@ class JpBuildInfo(C.Structure):
 
 
 JP_INTEGRATOR_PATH, JP_INTEGRATOR_WHITTED, JP_INTEGRATOR_DEBUG_NORMAL = 0, 1, 2
+JP_ABI_VERSION = 7      # include/jetpbrt_amd.h; hip_lib() refuses a library built for another ABI
+
+
+class JpOptions(C.Structure):
+    """ABI 7: the switches of the library by value (include/jetpbrt_amd.h: JpOptions); 0 = default, tri-state switches 1 on / -1 off"""
+    _fields_ = [("struct_bytes", C.c_int32), ("lanes", C.c_int32), ("lane_rows", C.c_int32), ("blocks_per_cu", C.c_int32), ("max_slots", C.c_int64),
+                ("compact_regions", C.c_int32), ("fused", C.c_int32), ("fused_region", C.c_int32), ("fused_job_spp", C.c_int32), ("fused_workgroups", C.c_int32),
+                ("traversal", C.c_int32), ("q4", C.c_int32), ("q4_shadow", C.c_int32), ("persist", C.c_int32), ("vote", C.c_int32), ("stack_lds_words", C.c_int32),
+                ("shade_sort", C.c_int32), ("device_tree", C.c_int32), ("device_wide", C.c_int32), ("bvh_max_leaf", C.c_int32), ("ploc_radius", C.c_int32), ("ploc_max_rounds", C.c_int32),
+                ("certified", C.c_int32), ("cert_slack", C.c_float), ("cert_slack_eye", C.c_float), ("cert_eye_tau", C.c_float),
+                ("libm_sincosf", C.c_int32), ("libm_xbsdf", C.c_int32), ("trace_walk", C.c_int32), ("box_pad", C.c_float), ("reserved", C.c_int32 * 8)]
 
 
 class JpBsdfDesc(C.Structure):
@@ -154,7 +165,11 @@ def hip_lib():
         if not os.path.exists(HIP_LIB_PATH):
             raise JetPbrtError("HIP library missing: %s (run __graft_entry__.build()); the product has no CPU fallback" % HIP_LIB_PATH)
         L = C.CDLL(HIP_LIB_PATH)
+        if L.jp_abi_version() != JP_ABI_VERSION:                 # (a stale or foreign build would be handed structs of the wrong size)
+            raise JetPbrtError("%s implements ABI %d, this binding ABI %d: rebuild with __graft_entry__.build()" % (HIP_LIB_PATH, L.jp_abi_version(), JP_ABI_VERSION))
         L.jp_last_error.restype = C.c_char_p
+        L.jp_set_options.argtypes = [C.c_void_p, C.POINTER(JpOptions)]
+        L.jp_get_options.argtypes = [C.c_void_p, C.POINTER(JpOptions)]
         L.jp_create_context.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.jp_destroy_context.argtypes = [C.c_void_p]
         L.jp_upload_scene.argtypes = [C.c_void_p, C.POINTER(JpScene)]
@@ -183,6 +198,25 @@ class Context:
     def _check(self, st):
         if st != JP_OK:
             raise JetPbrtError("jetpbrt_amd status %d: %s" % (st, self.lib.jp_last_error().decode()))
+
+    def get_options(self):
+        o = JpOptions()
+        self._check(self.lib.jp_get_options(self.h, C.byref(o)))
+        return o
+
+    def set_options(self, **kw):
+        """jp_set_options: the options in force with the given fields changed (e.g. lanes=1, persist=-1); no arguments: back to the initial value.
+        Traversal fields apply to the next upload, schedule fields to the next render."""
+        if not kw:
+            self._check(self.lib.jp_set_options(self.h, None))
+            return
+        o = self.get_options()
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise JetPbrtError("JpOptions has no field %r" % k)
+            setattr(o, k, v)
+        o.struct_bytes = C.sizeof(JpOptions)
+        self._check(self.lib.jp_set_options(self.h, C.byref(o)))
 
     def upload(self, scene_ptr):
         self._check(self.lib.jp_upload_scene(self.h, scene_ptr))

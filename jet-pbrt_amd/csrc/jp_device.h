@@ -68,7 +68,6 @@ struct SceneView
 	JpCamera cam;
 	const float4* flat; int n_flat;        // tiny scenes: <= 32 leaf boxes with the bit set of their primitives (<= 64), flat_boxes
 	const uint4* wide; int n_wide;          // large scenes: 8-wide quantised nodes, 5 x 16 bytes each (traverse_wide)
-	const float4* cut; int n_cut;           // other than tiny scenes: boxes of the <= 16 largest subtrees below the root in the flat_boxes layout (one bit each): the sort key of k_extend_sort / k_shadow_sort
 	const uint4* q4; int n_q4;              // large scenes: 4-wide tree with quantised child boxes, 4 x 16 bytes per node (Walker<4>)
 	const float4* refbox; float cert_pad, cert_pad_eye;   // (cert_pad_eye: the slack for rays from the camera position, which the edge-on flags cover)  // reference semantics, certified walk (Walker<6>): per device primitive the exact box of its leaf in the caller's tree (min, max); distance-cull slack c in tmax + c * tmax^2
 };

@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(256) k_ploc_depth(const PlocNode* __restrict__
 
 // Same contract as lbvh_build (jp_lbvh.h).  Returns hipErrorNotReady when the clustering does not finish within the round limit (the caller
 // falls back to the LBVH topology); r is then untouched.
-static hipError_t ploc_build(hipStream_t stream, const float4* prims0, const int4* meta0, int n, int maxLeaf, LbvhResult& r, std::vector<int>& order)
+static hipError_t ploc_build(hipStream_t stream, const float4* prims0, const int4* meta0, int n, int maxLeaf, int opt_radius, int opt_max_rounds, LbvhResult& r, std::vector<int>& order)
 {
 	if (n < 2) return lbvh_build(stream, prims0, meta0, n, maxLeaf, r, order);
 	hipError_t e = hipSuccess;
@@ -241,9 +241,9 @@ static hipError_t ploc_build(hipStream_t stream, const float4* prims0, const int
 	hipLaunchKernelGGL(k_lbvh_gather, dim3(grid), dim3(256), 0, stream, (const int*)vals2, n, prims0, meta0, (const float4*)lo0, (const float4*)hi0, primsS, metaS, lo, hi);
 	hipLaunchKernelGGL(k_ploc_init, dim3(grid), dim3(256), 0, stream, (const float4*)lo, (const float4*)hi, n, ca);
 	int radius = JP_PLOC_RADIUS;                                   // measured on the 280k-triangle scene (profiles/r03g_ploc_ab.txt)
-	if (const char* ev = getenv("JETPBRT_PLOC_RADIUS")) { const int v = atoi(ev); if (v >= 1 && v <= 256) radius = v; }
+	if (opt_radius >= 1 && opt_radius <= 256) radius = opt_radius;   // JpOptions::ploc_radius
 	int max_rounds = 512;                                          // ~40 rounds for 280k primitives; the limit guards against a build that does not converge
-	if (const char* ev = getenv("JETPBRT_PLOC_MAX_ROUNDS")) { const int v = atoi(ev); if (v >= 1) max_rounds = v; }   // (test hook: forces the LBVH fallback)
+	if (opt_max_rounds >= 1) max_rounds = opt_max_rounds;          // JpOptions::ploc_max_rounds (test hook: forces the LBVH fallback)
 	int m = n, next_id = 0, rounds = 0;
 	bool stuck = false;
 	while (m > 1)

@@ -24,6 +24,8 @@ struct HipApi
 	int (*render_rgb8)(JpContext*, const JpRenderParams*, uint8_t*, float*) = nullptr;
 	int (*bsdf)(JpContext*, const JpBsdfDesc*, int32_t, const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*, int32_t*) = nullptr;
 	int (*get_counters)(JpContext*, JpCounters*) = nullptr;
+	int (*abi_version)() = nullptr;
+	int (*set_options)(JpContext*, const JpOptions*) = nullptr;
 	std::string error;
 };
 
@@ -47,8 +49,12 @@ HipApi& Api()
 		api.get_counters = (int (*)(JpContext*, JpCounters*))dlsym(api.lib, "jp_get_counters");
 		api.render_rgb8 = (int (*)(JpContext*, const JpRenderParams*, uint8_t*, float*))dlsym(api.lib, "jp_render_rgb8");
 		api.bsdf = (decltype(api.bsdf))dlsym(api.lib, "jp_bsdf");
-		if (!api.last_error || !api.create_context || !api.destroy_context || !api.upload_scene || !api.render || !api.get_counters || !api.render_rgb8 || !api.bsdf)
+		api.abi_version = (int (*)())dlsym(api.lib, "jp_abi_version");
+		api.set_options = (int (*)(JpContext*, const JpOptions*))dlsym(api.lib, "jp_set_options");
+		if (!api.last_error || !api.create_context || !api.destroy_context || !api.upload_scene || !api.render || !api.get_counters || !api.render_rgb8 || !api.bsdf || !api.abi_version || !api.set_options)
 		{ api.error = "libjetpbrt_amd.so lacks a required jp_* symbol"; dlclose(api.lib); api.lib = nullptr; }
+		else if (api.abi_version() != JP_ABI_VERSION)            // a stale build would be handed structs of another size (JpCounters, JpBuildInfo, JpOptions)
+		{ api.error = "libjetpbrt_amd.so implements ABI " + std::to_string(api.abi_version()) + ", this host library was built for ABI " + std::to_string(JP_ABI_VERSION); dlclose(api.lib); api.lib = nullptr; }
 	});
 	return api;
 }
@@ -103,6 +109,7 @@ void FGpuPathIntegrator::Render(const FScene* scene, FSampler* sampler, FFilm* f
 	if (!api.lib) { fprintf(stderr, "FGpuPathIntegrator::Render: HIP library not available (%s); nothing rendered\n", api.error.c_str()); lastStatus = JP_ERR_NO_DEVICE; return; }
 	if (!scene || !sampler || !film) { fprintf(stderr, "FGpuPathIntegrator::Render: null argument\n"); lastStatus = JP_ERR_INVALID_ARGUMENT; return; }
 	if (!ctx) { lastStatus = api.create_context(deviceId, &ctx); if (lastStatus != JP_OK) { fprintf(stderr, "FGpuPathIntegrator::Render: %s\n", api.last_error()); ctx = nullptr; return; } }
+	if (optionsDirty) { lastStatus = api.set_options(ctx, &options); if (lastStatus != JP_OK) { fprintf(stderr, "FGpuPathIntegrator::Render: %s\n", api.last_error()); return; } optionsDirty = false; }
 	if (uploaded != scene)
 	{
 		FlatScene flat; std::string err;

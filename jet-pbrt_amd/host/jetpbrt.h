@@ -342,6 +342,7 @@ public:
 	// become flat leaf lists / LDS-resident trees, which need the host's leaves).  hostBuild = true or env JETPBRT_DEVICE_BVH=0 keep the
 	// host build for every scene, deviceBuild = true or JETPBRT_DEVICE_BVH=1 force the device build.
 	bool deviceBuild = false, hostBuild = false;
+	bool builtOnDevice = false;                                  // what the last Preprocess() decided (read-only for callers)
 	static constexpr size_t kDeviceBuildFrom = 4096;
 	// true: Preprocess() builds the reference's own tree (BuildReferenceBVH: its rand() sequence from the default seed, its
 	// std::sort, median split, leaves <= 5, over the reference's WorldBounds) and the flattened scene asks the device to walk
@@ -396,7 +397,13 @@ public:
 	const JpCounters& Counters() const { return counters; }
 	// multi-GPU band sharding (JpRenderParams::shard_*); default renders the whole film
 	void SetShard(int index, int count, int bandRows = 20) { shardIndex = index; shardCount = count; this->bandRows = bandRows; }
+	// ABI 7: the library's switches by value (JpOptions of include/jetpbrt_amd.h: stream lanes, traversal overrides, certified-walk slack, ...);
+	// zero-initialised = the defaults.  Handed to jp_set_options before the next upload / render.
+	void SetOptions(const JpOptions& o) { options = o; options.struct_bytes = (int32_t)sizeof(JpOptions); optionsDirty = true; uploaded = nullptr; }
+	const JpOptions& Options() const { return options; }
 protected:
+	JpOptions options = {};
+	mutable bool optionsDirty = false;
 	int maxDepth, deviceId;
 	int shardIndex = 0, shardCount = 1, bandRows = 20;
 	mutable JpContext* ctx = nullptr;

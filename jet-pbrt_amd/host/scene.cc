@@ -227,6 +227,7 @@ void FScene::Preprocess()                                                // scen
 	worldBound = bound;
 	for (auto& l : lights) l->Preprocess(*this);
 	if (const char* e = getenv("JETPBRT_REFERENCE_TREE")) { if (atoi(e) == 1 || atoi(e) == 2) referenceTree = true; if (atoi(e) == 2) certifiedWalk = true; }
+	builtOnDevice = false;
 	if (referenceTree)
 	{
 		std::vector<FBounds3> wb; wb.reserve(primitives.size());
@@ -235,10 +236,11 @@ void FScene::Preprocess()                                                // scen
 		preprocessed = true;
 		return;
 	}
+	// (the decision goes to builtOnDevice: deviceBuild / hostBuild stay what the caller set, so a later Preprocess() of a changed scene decides afresh)
 	bool dev = deviceBuild || (!hostBuild && primitives.size() > kDeviceBuildFrom);
 	if (const char* e = getenv("JETPBRT_DEVICE_BVH")) dev = atoi(e) == 1 ? true : (atoi(e) == 0 ? false : dev);
-	deviceBuild = dev;
-	if (deviceBuild) { bvh = FlatBVH(); preprocessed = true; return; }
+	builtOnDevice = dev;
+	if (builtOnDevice) { bvh = FlatBVH(); preprocessed = true; return; }
 	std::vector<FBounds3> pb; pb.reserve(primitives.size());
 	// own BVH over the exact extents: a ray leaving a flat surface (min_t 0.001) or ending 0.001 short of a light
 	// then misses that surface's box instead of visiting its leaf through the reference's 0.01 thinness pad

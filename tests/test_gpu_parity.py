@@ -368,18 +368,21 @@ def test_batching_and_region_layout_do_not_change_the_film(H, gpu_ctx, monkeypat
     gpu_ctx.upload(sp)
     p = H.jp.render_params(W, Hh, spp, 5, 21)
     base = gpu_ctx.render(p)
-    for slots, bpc in ((W * Hh * 5, "3"), (W * Hh, "16"), (W * Hh * 24, "1"), (W * Hh * 7, "64")):
-        monkeypatch.setenv("JETPBRT_MAX_SLOTS", str(slots))
-        ctx2 = H.jp.Context(0)
-        try:
-            monkeypatch.setenv("JETPBRT_BLOCKS_PER_CU", bpc)
-            ctx3 = H.jp.Context(0)                       # blocks-per-CU is read at context creation
-            ctx3.upload(sp)
-            other = ctx3.render(p)
-            ctx3.close()
-        finally:
-            ctx2.close()
+    for slots, bpc in ((W * Hh * 5, 3), (W * Hh, 16), (W * Hh * 24, 1), (W * Hh * 7, 64)):
+        gpu_ctx.set_options(max_slots=slots, blocks_per_cu=bpc)   # ABI 7: JpOptions, schedule fields apply to the next render
+        other = gpu_ctx.render(p)
         assert np.array_equal(other.view(np.uint32), base.view(np.uint32)), (slots, bpc)
+    gpu_ctx.set_options()
+    # ... and the environment still seeds the options of a NEW context (read once, in jp_create_context)
+    monkeypatch.setenv("JETPBRT_MAX_SLOTS", str(W * Hh * 5)); monkeypatch.setenv("JETPBRT_BLOCKS_PER_CU", "3")
+    ctx3 = H.jp.Context(0)
+    try:
+        o = ctx3.get_options()
+        assert o.max_slots == W * Hh * 5 and o.blocks_per_cu == 3
+        ctx3.upload(sp)
+        assert np.array_equal(ctx3.render(p).view(np.uint32), base.view(np.uint32))
+    finally:
+        ctx3.close()
     monkeypatch.delenv("JETPBRT_MAX_SLOTS"); monkeypatch.delenv("JETPBRT_BLOCKS_PER_CU")
 
 
@@ -416,11 +419,10 @@ def test_wide_bvh_closest_hit_records(H, gpu_ctx, tmp_path, monkeypatch):
     L.jp_oracle_trace(oh, m, H.ptr(o), H.ptr(d), H.ptr(tmin), H.ptr(tmax), H.ptr(ohit), H.ptr(ot), H.ptr(oprim), H.ptr(onrm), H.ptr(opos))
     L.jp_oracle_scene_free(oh)
     for wide in (False, True):
-        if wide:
-            monkeypatch.setenv("JETPBRT_TRACE_WIDE", "1")
+        gpu_ctx.set_options(trace_walk=2 if wide else 0)          # JpOptions::trace_walk = 2: closest hits through the 8-wide tree
         hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
         assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)) and (prim == oprim).mean() > 0.9999, wide
-    monkeypatch.delenv("JETPBRT_TRACE_WIDE")
+    gpu_ctx.set_options()
     assert ohit.mean() > 0.3
 
 
@@ -526,11 +528,11 @@ def test_device_built_hierarchy_edge_cases(H, gpu_ctx, tmp_path):
     ohit, ot, oprim, onrm = _oracle_trace(H, sp, o, d, tmin, tmax)
     assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)) and (prim == oprim).mean() > 0.9999
     assert gpu_ctx.build_info().traversal_mode == 3               # the 8-wide shadow tree was collapsed on the device too
-    os.environ["JETPBRT_TRACE_WIDE"] = "1"                         # test hook: closest hits through the device-built wide tree
+    gpu_ctx.set_options(trace_walk=2)                              # test hook: closest hits through the device-built wide tree
     try:
         hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
     finally:
-        del os.environ["JETPBRT_TRACE_WIDE"]
+        gpu_ctx.set_options()
     assert np.array_equal(hit, ohit) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)) and (prim == oprim).mean() > 0.9999
     p = H.jp.render_params(64, 48, 8, 5, 3)
     ref, _ = H.oracle_render(sp, p, 8)
@@ -560,20 +562,18 @@ def test_two_lanes_render_the_same_film_as_one(H, gpu_ctx, monkeypatch):
     gpu_ctx.upload(sp)
     for params in (H.jp.render_params(96, 100, 16, 5, 21), H.jp.render_params(96, 100, 8, 5, 21, band_rows=20, shard_index=1, shard_count=2),
                    H.jp.render_params(96, 100, 8, 3, 5, band_rows=7), H.jp.render_params(96, 17, 4, 5, 5)):
-        monkeypatch.setenv("JETPBRT_LANES", "1")
+        gpu_ctx.set_options(lanes=1)
         one = gpu_ctx.render(params); c1 = gpu_ctx.counters()
-        for lanes, rows in (("2", None), ("3", None), ("4", "1"), ("3", "7")):
-            monkeypatch.setenv("JETPBRT_LANES", lanes)            # force the split (by default only large frames use it)
-            if rows: monkeypatch.setenv("JETPBRT_LANE_ROWS", rows)
+        for lanes, rows in ((2, 0), (3, 0), (4, 1), (3, 7)):
+            gpu_ctx.set_options(lanes=lanes, lane_rows=rows)      # force the split (by default only large frames use it)
             two = gpu_ctx.render(params); c2 = gpu_ctx.counters()
             again = gpu_ctx.render(params)
-            if rows: monkeypatch.delenv("JETPBRT_LANE_ROWS")
             assert np.array_equal(one.view(np.uint32), two.view(np.uint32)) and np.array_equal(two.view(np.uint32), again.view(np.uint32)), (lanes, rows)
             assert (c1.samples, c1.closest_rays, c1.shadow_rays, c1.closest_hits) == (c2.samples, c2.closest_rays, c2.shadow_rays, c2.closest_hits)
             assert 2 <= gpu_ctx.build_info().lanes_last_render <= int(lanes)
     ref, _ = H.oracle_render(sp, H.jp.render_params(96, 100, 16, 5, 21), 4)
     assert l2(gpu_ctx.render(H.jp.render_params(96, 100, 16, 5, 21)), ref) < TOL_L2
-    monkeypatch.delenv("JETPBRT_LANES")
+    gpu_ctx.set_options()
 
 
 def test_full_material_benchmark_size(H, gpu_ctx):
@@ -631,11 +631,11 @@ def test_large_scene_benchmark_geometry_800x600(H, gpu_ctx):
     print("band vs reference tree: exact px %.5f mean L2 %.2e | vs watertight tree: exact px %.5f mean L2 %.2e" % (exact, d.mean(), exact_t, dt.mean()))
     assert exact_t > 0.97 and dt.mean() < 1e-3 and exact_t >= exact - 0.002
     assert abs(c.closest_rays / c.samples - 2.06) < 0.05
-    os.environ["JETPBRT_LANES"] = "2"
+    gpu_ctx.set_options(lanes=2)
     try:
         two = gpu_ctx.render(H.jp.render_params(W, Hh, spp))
     finally:
-        del os.environ["JETPBRT_LANES"]
+        gpu_ctx.set_options()
     assert np.array_equal(two.view(np.uint32), film.view(np.uint32))
 
 
@@ -1134,8 +1134,7 @@ def test_host_reflection_classes_and_other_samplers(H, gpu_ctx):
 
 @pytest.mark.parametrize("name", ["misc", "bunny_small", "lights"])
 def test_wavefront_sorts_and_lane_refill_do_not_change_the_film(H, gpu_ctx, monkeypatch, name):
-    """the round-2 scheduling changes only move work between lanes: material sort in k_shade on / off, ray sort in the traversal
-    kernels, lane refill (k_extend_persist / k_shadow_persist) with every refill threshold and with / without the vote, on the binary
+    """the round-2 scheduling changes only move work between lanes: material sort in k_shade on / off, lane refill (k_extend_persist / k_shadow_persist) with every refill threshold and with / without the vote, on the binary
     tree (mode 0, forced), the 8-wide shadow tree and the reference tree, a scene with a null-material primitive (extra iterations),
     tiny regions (one workgroup per 256 slots) and a region count that leaves most lanes without a ray, traversal stacks that spill
     to global memory after 2 or 4 words -- all bit-identical"""
@@ -1157,7 +1156,7 @@ def test_wavefront_sorts_and_lane_refill_do_not_change_the_film(H, gpu_ctx, monk
         return film, (c.closest_rays, c.closest_hits, c.shadow_rays, c.shadow_occluded), mode
 
     base, cnt, mode = render({"JETPBRT_SHADE_SORT": "0", "JETPBRT_PERSIST": "0"})
-    variants = [{"JETPBRT_SHADE_SORT": "1", "JETPBRT_PERSIST": "0"}, {"JETPBRT_RAY_SORT": "1", "JETPBRT_PERSIST": "0"}]
+    variants = [{"JETPBRT_SHADE_SORT": "1", "JETPBRT_PERSIST": "0"}]
     if mode != 2:                                                  # walked through global memory: the refill kernels apply
         variants += [{"JETPBRT_PERSIST": r, "JETPBRT_VOTE": v} for r in ("8", "16", "32") for v in ("0", "1")]
         variants += [{"JETPBRT_PERSIST": "16", "JETPBRT_BLOCKS_PER_CU": "64"}, {"JETPBRT_PERSIST": "16", "JETPBRT_MAX_SLOTS": str(W * Hh)}]
@@ -1262,9 +1261,9 @@ def test_four_wide_quantised_tree_hit_records_and_film(H, monkeypatch):
     try:
         assert c4.build_info().traversal_mode == 3 and c4.build_info().q4_nodes > 1000
         hit, t, prim, nrm = c4.trace(o, d, tmin, tmax)
-        monkeypatch.setenv("JETPBRT_TRACE_BINARY", "1")
+        c4.set_options(trace_walk=1)                              # the same rays through the binary tree
         hit2, t2, prim2, nrm2 = c4.trace(o, d, tmin, tmax)
-        monkeypatch.delenv("JETPBRT_TRACE_BINARY")
+        c4.set_options()
         film4 = c4.render(H.jp.render_params(W, Hh, spp, 5, 9)); cnt4 = c4.counters()
     finally:
         c4.close()
@@ -1277,7 +1276,6 @@ def test_four_wide_quantised_tree_hit_records_and_film(H, monkeypatch):
     assert np.array_equal(hit, hit2) and np.array_equal(t.view(np.uint32), t2.view(np.uint32)) and (prim == prim2).mean() > 0.9999
     for env in ({"JETPBRT_Q4": "0"}, {"JETPBRT_Q4_SHADOW": "0"}, {"JETPBRT_STACK_LDS": "2"}, {"JETPBRT_PERSIST": "8", "JETPBRT_VOTE": "0"},
                 {"JETPBRT_COMPACT_REGIONS": "0"}, {"JETPBRT_COMPACT_REGIONS": "1", "JETPBRT_LANES": "3"}, {"JETPBRT_COMPACT_REGIONS": "1", "JETPBRT_MAX_SLOTS": str(5 * 160 * 120)},   # region <- chunk mapping of k_raygen
-                {"JETPBRT_DUAL": "1"}, {"JETPBRT_DUAL": "1", "JETPBRT_LANES": "2", "JETPBRT_Q4_SHADOW": "0"},                # k_shadow on a second stream beside the next k_extend
                 {"JETPBRT_FUSED": "1"}, {"JETPBRT_FUSED": "1", "JETPBRT_Q4_SHADOW": "0"}, {"JETPBRT_FUSED": "1", "JETPBRT_STACK_LDS": "4"}):   # (k_path<4, 4> / <4, 3>)
         c = ctx_with(env)
         try:

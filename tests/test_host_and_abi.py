@@ -21,7 +21,8 @@ def test_abi_exports_every_declared_symbol(H):
     lib = C.CDLL(H.jp.HIP_LIB_PATH)
     for n in names:
         assert hasattr(lib, n), "libjetpbrt_amd.so does not export %s" % n
-    assert lib.jp_abi_version() == 6
+    assert lib.jp_abi_version() == 7 == H.jp.JP_ABI_VERSION
+    assert {"jp_set_options", "jp_get_options"} <= set(names)          # ABI 7: the switches by value
 
 
 def test_abi_struct_layout_matches_header(H):
@@ -30,8 +31,9 @@ def test_abi_struct_layout_matches_header(H):
     #include "jetpbrt_amd.h"
     #include <stdio.h>
     #include <stddef.h>
-    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(JpScene), sizeof(JpRenderParams), sizeof(JpCounters), sizeof(JpCamera),
-                offsetof(JpScene, bvh_prim_index), offsetof(JpScene, world_radius), sizeof(JpBuildInfo), offsetof(JpBuildInfo, device_build_ms)); return 0; }'''
+    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(JpScene), sizeof(JpRenderParams), sizeof(JpCounters), sizeof(JpCamera),
+                offsetof(JpScene, bvh_prim_index), offsetof(JpScene, world_radius), sizeof(JpBuildInfo), offsetof(JpBuildInfo, device_build_ms),
+                sizeof(JpOptions), offsetof(JpOptions, max_slots), offsetof(JpOptions, cert_slack), offsetof(JpOptions, reserved)); return 0; }'''
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
@@ -40,7 +42,8 @@ def test_abi_struct_layout_matches_header(H):
     jp = H.jp
     assert [int(v) for v in out] == [C.sizeof(jp.JpScene), C.sizeof(jp.JpRenderParams), C.sizeof(jp.JpCounters), C.sizeof(jp.JpCamera),
                                      jp.JpScene.bvh_prim_index.offset, jp.JpScene.world_radius.offset,
-                                     C.sizeof(jp.JpBuildInfo), jp.JpBuildInfo.device_build_ms.offset]
+                                     C.sizeof(jp.JpBuildInfo), jp.JpBuildInfo.device_build_ms.offset,
+                                     C.sizeof(jp.JpOptions), jp.JpOptions.max_slots.offset, jp.JpOptions.cert_slack.offset, jp.JpOptions.reserved.offset]
 
 
 def test_device_build_flag_flattens_without_a_hierarchy(H):
@@ -55,6 +58,22 @@ def test_device_build_flag_flattens_without_a_hierarchy(H):
     n = a.n_primitives
     for f in ("prim_shape_type", "prim_shape_index", "prim_material", "prim_light"):
         assert np.array_equal(np.ctypeslib.as_array(getattr(a, f), (n,)), np.ctypeslib.as_array(getattr(b, f), (n,)))
+
+
+def test_library_reads_the_environment_in_one_place_only(H):
+    """ABI 7: the kernel library's switches are JpOptions; the environment is read once per context by ONE table-driven loader
+    (round 3 had 42 getenv call sites that were consulted at upload / render time)"""
+    csrc = os.path.join(H.REPO, "jet-pbrt_amd", "csrc")
+    n = 0
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            n += len(re.findall(r"\bgetenv\s*\(", open(os.path.join(csrc, f), errors="ignore").read()))
+    assert n == 1, n
+    hdr = open(os.path.join(H.REPO, "include", "jetpbrt_amd.h")).read()
+    fields = re.findall(r"^\s+(?:int32_t|int64_t|float)\s+([a-z_0-9, ]+);", hdr[hdr.index("typedef struct JpOptions"):hdr.index("} JpOptions;")], re.M)
+    names = [x.strip() for f in fields for x in f.split(",")]
+    mirror = [n for n, _ in H.jp.JpOptions._fields_]
+    assert [n.split("[")[0] for n in names] + ["reserved"] == mirror or [n.split("[")[0] for n in names] == mirror, (names, mirror)
 
 
 def test_product_does_not_reference_oracle(H):
@@ -306,12 +325,15 @@ def test_kernel_register_budgets(H, tmp_path):
     for name in ("k_extend<2>", "k_extend<0>", "k_extend_persist<0, 16, true>", "k_shadow_persist<3, 16, true>", "k_extend_persist<5, 16, false>",
                  "k_extend_persist<4, 16, true>", "k_shadow_persist<4, 16, true>"):
         assert rows[name]["vgpr"] <= 64 and rows[name]["waves"] == 8 and rows[name]["scratch"] == 0, (name, rows[name])
-    for name in ("k_extend_persist<6, 16, true>", "k_shadow_persist<6, 16, true>"):      # the certified walk: the 4-wide walk + certificate + the verbatim walk behind it
-        assert rows[name]["vgpr"] <= 72 and rows[name]["waves"] >= 7 and rows[name]["scratch"] == 0, (name, rows[name])
+    # the certified walk (the 4-wide walk + certificate + the verbatim walk behind it): round 4 compiles it for 8 waves per SIMD too -- measured +4 % over 7 waves
+    # (profiles/r04e_certified_waves.txt); the shadow kernel then keeps ONE 64-bit value in scratch, the pointer into the global stack-spill area, reloaded only on
+    # the spill path that almost no ray reaches
+    for name in ("k_extend_persist<6, 16, true>", "k_shadow_persist<6, 16, true>"):
+        assert rows[name]["vgpr"] <= 64 and rows[name]["waves"] == 8 and rows[name]["scratch"] <= 8, (name, rows[name])
     assert rows["k_shadow<2>"]["waves"] >= 6
     # (k_path, the opt-in fused schedule: register allocation aimed at 3 waves per SIMD, a few phase-level values spill outside its inner loops)
     assert all(r["waves"] >= 3 for n, r in rows.items() if n.startswith("k_path"))
-    spills = [n for n, r in rows.items() if r["scratch"] and not n.startswith(("k_other", "k_wide_level", "k_path"))]
+    spills = [n for n, r in rows.items() if r["scratch"] and not n.startswith(("k_other", "k_wide_level", "k_path", "k_shadow_persist<6", "k_extend_persist<6"))]
     assert not spills, spills
 
 

@@ -35,10 +35,9 @@ def main():
             ctx.render(p)                                       # warm: allocations, lanes, clocks
             t0 = time.perf_counter(); film = ctx.render(p); film = ctx.render(p); dt = (time.perf_counter() - t0) / 2
             lanes = ctx.build_info().lanes_last_render
-            os.environ["JETPBRT_LANES"] = kv.get("JETPBRT_LANES", "1")
+            ctx.set_options(lanes=int(kv.get("JETPBRT_LANES", "1")))       # (the environment is read when the context is created; a live context takes JpOptions)
             ctx.set_profiling(True); ctx.render(p); c = ctx.counters(); ctx.set_profiling(False)
-            if "JETPBRT_LANES" not in kv:
-                del os.environ["JETPBRT_LANES"]
+            ctx.set_options()
             same = "-" if ref is None else ("bit-identical" if np.array_equal(ref.view(np.uint32), film.view(np.uint32)) else "DIFFERENT mean L2 %.3e, identical px %.5f" % (
                 float(np.sqrt(((film - ref) ** 2).sum(-1)).mean()), float((film == ref).all(-1).mean())))
             if ref is None:

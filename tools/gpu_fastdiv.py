@@ -12,7 +12,7 @@ name, W, Hh, spp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv
 hb = H.scenes.build_bunny(H.scenes.HostBackend("f"), W, Hh) if name == "bunny" else H.SCENES[name](H.scenes.HostBackend("f"), W, Hh)
 ctx = jp.Context(0); ctx.upload(hb.flatten()); p = jp.render_params(W, Hh, spp)
 ctx.render(p); t0 = time.perf_counter(); f = ctx.render(p); f = ctx.render(p); dt = (time.perf_counter() - t0) / 2
-os.environ["JETPBRT_LANES"] = "1"; ctx.set_profiling(True); ctx.render(p); c = ctx.counters()
+ctx.set_options(lanes=1); ctx.set_profiling(True); ctx.render(p); c = ctx.counters()
 np.save(sys.argv[5], f)
 print("%%s %%dx%%dx%%d: %%.1f Msamples/s | 1 lane: extend %%.2f shade %%.2f shadow %%.2f ms" %% (name, W, Hh, spp, W * Hh * spp / dt / 1e6, c.extend_ms, c.shade_ms, c.shadow_ms), flush=True)
 ''' % (REPO, REPO)

@@ -20,11 +20,11 @@ d /= np.linalg.norm(d, axis=1, keepdims=True)
 o = np.tile(cam, (n, 1)).astype(np.float32)
 tmin = np.full(n, 0.001, np.float32); tmax = np.full(n, np.inf, np.float32)
 def both(o, d, label):
-    os.environ.pop("JETPBRT_TRACE_BINARY", None)
+    ctx.set_options()
     h4, t4, p4, n4 = ctx.trace(o, d, tmin[:len(o)], tmax[:len(o)])
-    os.environ["JETPBRT_TRACE_BINARY"] = "1"
+    ctx.set_options(trace_walk=1)
     h2, t2, p2, n2 = ctx.trace(o, d, tmin[:len(o)], tmax[:len(o)])
-    os.environ.pop("JETPBRT_TRACE_BINARY", None)
+    ctx.set_options()
     same = (h4 == h2) & (p4 == p2) & (t4.view(np.uint32) == t2.view(np.uint32))
     print("%s: %d rays, %d hits; identical records %d, different %d (4-wide nearer: %d, binary nearer: %d)" % (
         label, len(o), int(h4.sum()), int(same.sum()), int((~same).sum()), int(((~same) & (t4 < t2)).sum()), int(((~same) & (t2 < t4)).sum())), flush=True)
