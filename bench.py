@@ -79,7 +79,7 @@ def build_scene(scenes, backend, key, W, H):
 
 def load_profile_constants():
     """rocprofv3 figures measured in an earlier profiling run and committed under profiles/ (never measured inside this run)"""
-    for name in ("traffic_r03.json", "traffic_r02.json"):
+    for name in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):
         try:
             d = json.load(open(os.path.join(REPO, "profiles", name)))
             d["_file"] = "profiles/" + name
@@ -150,10 +150,13 @@ def roofline_record(c, c1, value, spp_total, n, lanes, scene_key, prof):
         if "valu_insts_per_unit" in pv:
             g = pv["valu_insts_per_unit"] * u1 / (ms1 * 1e-3) / 1e9
             e["valu_frac"] = round(g / VALU_PEAK_GINST, 3); e["lane_util"] = pv.get("lane_utilisation")
+            e["simd_cycles_per_valu_inst"] = round(256 * 4 * VALU_CLOCK_GHZ / g, 2)   # 2.5-2.8: a pure v_add / v_mul stream; 3.9-4.4: fma / min / max / cmp / cvt / cndmask; the kernels' mix is ~85 % the latter (profiles/r04a_valu_issue_cost.txt)
+        if "valu_busy" in pv:                                # [round 4] VALUBusy by rocprofv3's derived-metric formula, from the PMC pass (every dispatch profiled on its own)
+            e["valu_busy_pmc"] = pv["valu_busy"]
         alone[k] = e
     roof["alone" if c1 is not None else "per_class"] = alone
     roof["notes"] = {"alone": "one extra untimed step on ONE stream lane: every kernel has the GPU to itself" if c1 is not None else "from the timed configuration",
-                     "valu_peak": "256 CUs x 4 SIMDs x %.1f GHz / 2 cycles = %.0f G wave64 instructions/s" % (VALU_CLOCK_GHZ, VALU_PEAK_GINST),
+                     "valu_peak": "256 CUs x 4 SIMDs x %.1f GHz / 2 cycles = %.0f G wave64 instructions/s -- reachable only by v_add / v_mul / v_and; this mix (fma, min / max, compare, convert: ~4 cycles; IEEE division 42) saturates at about half of it: valu_busy (profiles/r04a_valu_issue_cost.txt)" % (VALU_CLOCK_GHZ, VALU_PEAK_GINST),
                      "pmc": "%s: rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE and SQ_INSTS_VALU per unit, measured in an earlier profiling run of this scene" % prof.get("_file", "-")}
     return roof
 
@@ -507,6 +510,7 @@ def main():
             out["config"]["sub"] = {k.replace("configs[", "c").replace("]", ""): {
                 "Msamples_s": v["value"], "ms": v["ms_per_step"], "frames": v["steps"], "s": v["timed_region_s"], "whole_path_frac": v["roofline"]["whole_path"]["frac"],
                 "dominant": v["roofline"]["kernel"], "frac": v["roofline"]["frac"],
+                "cyc_per_valu": {k2.replace("k_", ""): e2.get("simd_cycles_per_valu_inst") for k2, e2 in (v["roofline"].get("alone") or {}).items() if isinstance(e2, dict) and "simd_cycles_per_valu_inst" in e2} or None,
                 "l2": (None if not v.get("l2_vs_cpu_ref") else r4(v["l2_vs_cpu_ref"]["mean_per_pixel_l2"])),
                 "identical": (None if not v.get("l2_vs_cpu_ref") else (v["l2_vs_cpu_ref"].get("bit_identical") if "bit_identical" in v["l2_vs_cpu_ref"] else round(v["l2_vs_cpu_ref"].get("fraction_pixels_identical", 0), 4))),
                 "cpu_ref_Msamples_s": (None if not v.get("cpu_baseline") else v["cpu_baseline"]["value"]),

@@ -313,6 +313,81 @@ def test_bunny_scene_full_bvh(H, gpu_ctx):
     assert abs(c.closest_rays - cnt.closest_rays) <= max(8, cnt.closest_rays * 2e-4)
 
 
+def test_options_by_value_abi7(H, gpu_ctx, monkeypatch):
+    """ABI 7: JpOptions through jp_set_options / jp_get_options -- defaults are zeros, fields are validated, schedule fields act on the next render and traversal
+    fields on the next upload, NULL restores the initial value, and the environment only seeds a NEW context"""
+    jp = H.jp
+    o = gpu_ctx.get_options()
+    assert o.struct_bytes == C.sizeof(jp.JpOptions) and o.lanes == 0 and o.persist == 0 and o.q4 == 0 and o.cert_slack == 0.0 and o.trace_walk == 0
+    for bad in (dict(lanes=5), dict(lanes=-1), dict(persist=12), dict(traversal=9), dict(trace_walk=4), dict(bvh_max_leaf=17), dict(device_tree=3)):
+        with pytest.raises(jp.JetPbrtError):
+            gpu_ctx.set_options(**bad)
+    assert gpu_ctx.get_options().lanes == 0                        # a refused struct changes nothing
+    W, Hh = 96, 64
+    hb, sp = _scene(H, "bunny_small", W, Hh)
+    gpu_ctx.upload(sp)
+    p = jp.render_params(W, Hh, 4, 5, 3)
+    base = gpu_ctx.render(p); b0 = gpu_ctx.build_info()
+    assert b0.q4_nodes > 0                                         # 3,074 primitives: the 4-wide tree, refill kernels
+    gpu_ctx.set_options(lanes=2, lane_rows=3)
+    two = gpu_ctx.render(p)
+    assert gpu_ctx.build_info().lanes_last_render == 2 and np.array_equal(two.view(np.uint32), base.view(np.uint32))
+    gpu_ctx.set_options(lanes=1, q4=-1, persist=-1)                # traversal fields: nothing changes until the next upload
+    assert gpu_ctx.build_info().q4_nodes == b0.q4_nodes
+    gpu_ctx.upload(sp)
+    assert gpu_ctx.build_info().q4_nodes == 0 and gpu_ctx.get_options().q4 == -1
+    one = gpu_ctx.render(p)
+    assert gpu_ctx.build_info().lanes_last_render == 1 and l2(one, base) < 1e-5   # (another tree may move a fringe hit: DESIGN.md "Numerics")
+    gpu_ctx.set_options()                                          # back to the initial value
+    assert gpu_ctx.get_options().q4 == 0 and gpu_ctx.get_options().lanes == 0
+    gpu_ctx.upload(sp)
+    assert gpu_ctx.build_info().q4_nodes == b0.q4_nodes and np.array_equal(gpu_ctx.render(p).view(np.uint32), base.view(np.uint32))
+    monkeypatch.setenv("JETPBRT_Q4", "0"); monkeypatch.setenv("JETPBRT_CERT_SLACK", "512"); monkeypatch.setenv("JETPBRT_PERSIST", "0")
+    assert gpu_ctx.get_options().q4 == 0                           # a live context never looks at the environment again
+    c2 = jp.Context(0)
+    try:
+        e = c2.get_options()
+        assert e.q4 == -1 and e.cert_slack == 512.0 and e.persist == -1
+        c2.set_options(q4=1)
+        assert c2.get_options().q4 == 1 and c2.get_options().cert_slack == 512.0
+    finally:
+        c2.close()
+    monkeypatch.delenv("JETPBRT_Q4"); monkeypatch.delenv("JETPBRT_CERT_SLACK"); monkeypatch.delenv("JETPBRT_PERSIST")
+
+
+def test_trace_and_whitted_on_the_default_built_large_scene(H, gpu_ctx):
+    """round-3 advisor item: the one-ray-per-lane kernels (k_trace<4>, k_other<0>) keep the WHOLE traversal stack in LDS and had no size guard once the
+    default tree of the 280k-triangle scene became the device-built PLOC tree with its 4-wide collapse.  Round 4: the 4-wide walks have their own stack depth
+    (3 x height + 2 words), every launch that needs it is guarded (<= 64 KB, else the binary walk), the binary / verbatim kernels are sized by the binary height
+    again.  jp_trace (the 4-wide walk AND the binary walk) and a Whitted render on that scene, against the oracle."""
+    W, Hh = 96, 72
+    hb = H.scenes.build_bunny(H.scenes.HostBackend("bunny"), W, Hh)
+    sp = hb.flatten()
+    assert sp.contents.n_bvh_nodes == 0                            # built on the device by default (> 4096 primitives)
+    gpu_ctx.upload(sp)
+    bi = gpu_ctx.build_info()
+    assert bi.built_on_device == 1 and bi.q4_nodes > 10000 and bi.traversal_mode == 3
+    rng = np.random.default_rng(11); m = 60000
+    cam = np.array([-300, 300, -300], np.float32)
+    tgt = np.stack([rng.uniform(-150, 60, m), rng.uniform(0, 120, m), rng.uniform(-150, 60, m)], 1).astype(np.float32)
+    o = np.tile(cam, (m, 1)); o[m // 2:] = tgt[m // 2:] + rng.normal(size=(m - m // 2, 3)).astype(np.float32) * 40   # camera rays and rays from inside the scene
+    d = (tgt - o) if False else rng.normal(size=(m, 3)).astype(np.float32); d[: m // 2] = tgt[: m // 2] - cam
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    tmin = np.full(m, 0.001, np.float32); tmax = np.full(m, np.inf, np.float32)
+    ohit, ot, oprim, onrm = _oracle_trace(H, sp, o, d, tmin, tmax)
+    for walk in (0, 1):                                            # what the render walks (4-wide), then the binary tree
+        gpu_ctx.set_options(trace_walk=walk)
+        hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
+        same = (hit == ohit) & (t.view(np.uint32) == ot.view(np.uint32))
+        # (the oracle walks a reference-style tree: a handful of hits in the fp32 acceptance fringe differ by the tree, in both directions -- DESIGN.md "Numerics": measured 5 of 60,000)
+        assert same.mean() > 0.9995 and ohit.mean() > 0.2, (walk, same.mean())
+    gpu_ctx.set_options()
+    p = H.jp.render_params(W, Hh, 2, 4, 5, integrator=H.jp.JP_INTEGRATOR_WHITTED)
+    film = gpu_ctx.render(p)
+    ref, _ = H.oracle_render(sp, p, len(os.sched_getaffinity(0)))
+    assert np.isfinite(film).all() and film.mean() > 0.02 and l2(film, ref) < 1e-3, l2(film, ref)
+
+
 @pytest.mark.parametrize("seed,n_tris", [(1, 400), (2, 400), (3, 400), (4, 400), (5, 250), (6, 150), (7, 90)])
 def test_random_scenes(H, gpu_ctx, tmp_path, seed, n_tris):
     """random triangle soups, rectangles, spheres, every material, triangle / rectangle / sphere lights, env light; the sizes
