@@ -1011,6 +1011,19 @@ def test_config3_full_size_default_path_vs_reference_tree(H, gpu_ctx):
             assert np.array_equal(gband.view(np.uint32), oband.view(np.uint32))
         else:
             assert l2(gband, oband) < 1e-3
+        # [round 4] ... and at the FULL sample count: twelve single rows across the image (rows j % 50 == 37: twelve oracle tasks, 19.7 M samples, ~10 s on 16+ threads)
+        # of the full-size reference-tree film itself against the CPU oracle -- every sample index of the frame, 0 .. 2047, strictly
+        pf = H.jp.render_params(W, Hh, spp, band_rows=1, shard_index=37, shard_count=50)
+        H.libc_srand(1)
+        ofull, _ = H.oracle_render(rsp, pf, len(os.sched_getaffinity(0)))
+        frows = np.zeros(Hh, bool)
+        for y0, y1 in H.jp.distributed.bands_of(Hh, 37, 50, 1):
+            frows[y0:y1] = True
+        assert frows.sum() == 12
+        if rctx.build_info().libm_sincosf != 0:
+            assert np.array_equal(ref[frows].view(np.uint32), ofull[frows].view(np.uint32))
+        else:
+            assert l2(ref[frows], ofull[frows]) < 1e-3
     finally:
         rctx.close()
     # the certified walk over the same tree (FScene::certifiedWalk) at the full size against the verbatim film: bit-identical when measured
@@ -1106,6 +1119,8 @@ def test_bench_two_rank_rehearsal_on_one_gpu(H, gpu_ctx, tmp_path):
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak" and j["value"] > 0
     assert "64 spp" in j["config"]["workload"] and "band shard x2" in j["config"]["parallelism"]
+    sc = j["shard_check"]                                          # [round 4] the N > 1 run checks itself: ranks, per-rank sample counts, every rank's bands in the film
+    assert sc["ok"] and sc["world_size"] == 2 == sc["ranks_expected"] and sc["samples_per_rank"] == sc["samples_expected_per_rank"] and sc["samples_total"] == 256 * 256 * 64 and sc["ranks_with_empty_bands"] == []
     par = j["l2_vs_cpu_ref"]
     assert par is not None and par["mean_per_pixel_l2"] < TOL_L2
     if par["libm_sincosf"] != 0:
