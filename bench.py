@@ -26,7 +26,7 @@ in the assembled film (no rank's rows are all zero).
 Rank 0 prints one JSON line.  Besides the contract fields:
   roofline     : dominant kernel class, algorithmic bytes per launch / HIP-event launch duration (events on the kernel
                  stream, taken on the last step of the timed region) vs 8 TB/s HBM; `traffic` = rocprofv3 PMC bytes per unit
-                 (profiles/traffic_r03.json, named once in `notes`) x this run's units per launch; `attributed` = the same launch by
+                 (profiles/traffic_r04.json, named once in `notes`) x this run's units per launch; `attributed` = the same launch by
                  the bytes that kernel class itself moves; `alone` = every class with the GPU to itself: contract / attributed HBM
                  fraction and the vector-instruction issue fraction (instructions per unit from the SQ counter passes under profiles/)
   config.sub   : one compact summary per single-GPU BASELINE.json config (value, ms, whole-path fraction, parity, CPU reference);
