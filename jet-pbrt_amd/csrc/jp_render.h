@@ -568,7 +568,8 @@ int jp_get_build_info(JpContext* c, JpBuildInfo* out)
 	out->device_build_ms = c->build_ms; out->libm_sincosf = c->sincosf_mode; out->lanes_last_render = c->last_lanes;
 	out->fused_last_render = c->last_fused; out->fused_region = c->last_region; out->fused_workgroups = c->last_wgs;
 	out->q4_nodes = c->use_q4 ? c->sv.n_q4 : 0; out->libm_xbsdf = c->libm_mode;
-	out->certified_walk = (c->cert && c->persist != 0 && !c->cert_fell_back) ? 1 : 0;   // (what the refill kernels of the last render actually walked: the certified structures exist AND were used) out->certified_nodes = c->cert ? c->sv.n_q4 : 0; out->certified_eye_leaves = c->cert ? c->cert_eye_leaves : 0;
+	out->certified_walk = (c->cert && c->persist != 0 && !c->cert_fell_back) ? 1 : 0;   // (what the refill kernels of the last render actually walked: the certified structures exist AND were used)
+	out->certified_nodes = c->cert ? c->sv.n_q4 : 0; out->certified_eye_leaves = c->cert ? c->cert_eye_leaves : 0;
 	return JP_OK;
 }
 
