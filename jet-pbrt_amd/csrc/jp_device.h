@@ -617,7 +617,12 @@ template <bool kCert> struct WalkerQ4
 {
 	V3 o, d; float ix, iy, iz, tmin, tmax; int cur, sp, hit; bool done, unsure, from_eye;
 	__device__ __forceinline__ void start(V3 o_, V3 d_, float tmin_, float tmax_)
-	{ o = o_; d = d_; ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z; tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; done = false; unsure = kCert && (d.x == 0.f || d.y == 0.f || d.z == 0.f); from_eye = false; }
+	{
+		// reciprocal direction: the hardware approximation (1 ulp, 8 issue cycles against the 42 of an IEEE division -- three per ray): every slab distance of an axis is scaled by the same
+		// 1 +- 1.2e-7, far inside the 2e-6 slack of the box test below (the flat leaf list has always used it: flat_boxes); 0 and denormals give +-inf: the axis-parallel case
+		o = o_; d = d_; ix = __builtin_amdgcn_rcpf(d.x); iy = __builtin_amdgcn_rcpf(d.y); iz = __builtin_amdgcn_rcpf(d.z); tmin = tmin_; tmax = tmax_; cur = 0; sp = 0; hit = -1; done = false;
+		unsure = kCert && (d.x == 0.f || d.y == 0.f || d.z == 0.f); from_eye = false;
+	}
 	// kCert: a ray that starts at the camera position is not culled by distance at the children flagged "edge-on to the camera" (jp_upload_scene): the
 	// triangles whose plane passes through the eye are the ones a camera ray can lie in to within fp32 noise (see above)
 	__device__ __forceinline__ void mark_origin(const SceneView& sc) { from_eye = kCert && o.x == sc.cam.pos[0] && o.y == sc.cam.pos[1] && o.z == sc.cam.pos[2]; }
@@ -657,7 +662,7 @@ template <bool kCert> struct WalkerQ4
 			const float z0 = fmaf((float)((azn >> sh) & 0xffu), az, bz), z1 = fmaf((float)((azf >> sh) & 0xffu), az, bz);
 			const float t0 = fmaxf(fmaxf(x0, y0), fmaxf(z0, tmin));
 			const float tf = fminf(fminf(x1, y1), fminf(z1, (kCert && ((eyebits >> i) & 1u)) ? tcull_eye : tcull));
-			hc[i] = ((q0.w >> (24 + i)) & 1u) && t0 <= tf * 1.000002f;
+			hc[i] = t0 <= tf * 1.000002f;                             // (an unused slot holds the empty box lo = 255 > hi = 0 on every axis and a reference to primitive 0 as a one-primitive leaf: it fails here, and a pass would cost one harmless test -- no valid bit to check)
 			tn[i] = hc[i] ? fminf(t0, 3.0e38f) : JP_INF;             // a missed child ranks behind every hit one
 			nh += hc[i] ? 1 : 0;
 		}
@@ -667,11 +672,13 @@ template <bool kCert> struct WalkerQ4
 		int r[4] = { 0, 0, 0, 0 };
 		if (kAnyHit) { r[1] = hc[0] ? 1 : 0; r[2] = r[1] + (hc[1] ? 1 : 0); r[3] = r[2] + (hc[2] ? 1 : 0); }
 		else
-		{
-			#pragma unroll
-			for (int i = 0; i < 4; i++)
-				#pragma unroll
-				for (int j = i + 1; j < 4; j++) { const bool first = tn[i] <= tn[j]; r[j] += first ? 1 : 0; r[i] += first ? 0 : 1; }
+		{   // s_ij = 1 iff child j is entered before child i.  The entry distances are non-negative floats (>= tmin; a missed child: +inf), which order like their bit patterns, and
+			// two such patterns differ by less than 2^31: the sign bit of the integer difference is the comparison -- a subtraction and a shift of the 2.6-cycle class instead of a
+			// v_cmp + v_cndmask pair at 4.4 each (profiles/r04a_valu_issue_cost.txt); ties go to the lower child number, as before
+			// (written as instructions: from the expression `(unsigned)(bj - bi) >> 31` the compiler proves the operands non-negative and goes back to v_cmp_lt_i32 + v_cndmask)
+			auto before = [](float tj, float ti) -> int { int sgn; asm("v_sub_u32 %0, %1, %2\n\tv_lshrrev_b32 %0, 31, %0" : "=&v"(sgn) : "v"(tj), "v"(ti)); return sgn; };
+			const int s01 = before(tn[1], tn[0]), s02 = before(tn[2], tn[0]), s03 = before(tn[3], tn[0]), s12 = before(tn[2], tn[1]), s13 = before(tn[3], tn[1]), s23 = before(tn[3], tn[2]);
+			r[0] = s01 + s02 + s03; r[1] = 1 - s01 + s12 + s13; r[2] = 2 - s02 - s12 + s23; r[3] = 3 - s03 - s13 - s23;
 		}
 		// rank 0 is walked next, the others go on the stack, farthest first.  No branch per child: while the three possible entries
 		// fit the LDS part of the stack, every child stores -- the ones with nothing to push into the word behind the stack's LDS part

@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(64) k_q4_level(const float4* __restrict__ node
 		child_base = atomicAdd(q4_count, ninner); if (child_base + ninner > max_nodes) { *fail = 1; return; }
 		nbase = atomicAdd(next_count, ninner);
 	}
-	unsigned char ql[3][4], qh[3][4]; uint32_t refs[4] = { 0, 0, 0, 0 }, valid = 0, rank = 0;
+	unsigned char ql[3][4], qh[3][4]; uint32_t refs[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu }, valid = 0, rank = 0;   // unused slots: the empty box (255 > 0) and primitive 0 as a one-primitive leaf (-1): WalkerQ4 tests no valid bit
 	for (int k = 0; k < 4; k++) for (int a = 0; a < 3; a++) { ql[a][k] = 255; qh[a][k] = 0; }
 	for (int k = 0; k < nch; k++)
 	{

@@ -404,7 +404,7 @@ extern "C" int jp_upload_scene(JpContext* c, const JpScene* s)
 				e = std::max(-120, std::min(120, e));
 				eb[a] = e + 127; sc3[a] = std::ldexp(1.0f, e);
 			}
-			uint8_t ql[3][4], qh[3][4]; uint32_t refs[4] = { 0, 0, 0, 0 }, valid = 0, flags = 0;
+			uint8_t ql[3][4], qh[3][4]; uint32_t refs[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu }, valid = 0, flags = 0;   // unused slots: the empty box (255 > 0) and primitive 0 as a one-primitive leaf (-1): WalkerQ4 tests no valid bit
 			for (int k = 0; k < 4; k++) for (int a = 0; a < 3; a++) { ql[a][k] = 255; qh[a][k] = 0; }
 			for (int k = 0; k < nc && ok; k++)
 			{
