@@ -285,9 +285,15 @@ def main():
                 empty = [r for r in range(world) if not any(rows_filled[y0:y1].any() for y0, y1 in jp.distributed.bands_of(H, r, world, band_rows))]
                 shard_check["ranks_with_empty_bands"] = empty; shard_check["empty_rows"] = int((~rows_filled).sum()); shard_check["finite"] = bool(np.isfinite(film).all())
                 ok = ok and not empty and shard_check["finite"]
-            shard_check["ok"] = bool(ok)
+            # every rank learns the verdict (rank 0 alone sees the film): a failed check ends ALL ranks together instead of leaving the others in a collective
+            okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            ok = bool(int(okt.item()))
+            shard_check["ok"] = ok
             if not ok:
-                raise SystemExit("bench.py: the %d-rank frame is incomplete: %s" % (n, json.dumps(shard_check)))
+                if rank == 0:
+                    sys.stderr.write("bench.py: the %d-rank frame is incomplete: %s\n" % (n, json.dumps(shard_check)))
+                raise SystemExit(3)
         bi = ctx.build_info()
         lanes = int(bi.lanes_last_render)
         # With several lanes a launch shares the GPU with the other lanes' kernels, so its duration (and the per-launch roofline
