@@ -232,7 +232,7 @@ int make_lanes(JpContext* c, int extra)
 	while ((int)c->lanes.size() < extra)
 	{
 		JpContext* l = new JpContext;
-		l->device = c->device; l->is_lane = true; l->n_cus = c->n_cus; l->blocks_per_cu = c->blocks_per_cu;
+		l->device = c->device; l->is_lane = true; l->n_cus = c->n_cus; l->blocks_per_cu = c->blocks_per_cu; l->opt = c->opt; l->opt_env = c->opt_env;
 		std::memset(&l->counters, 0, sizeof(l->counters)); std::memset(&l->q, 0, sizeof(l->q));
 		if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&l->ev0) != hipSuccess || hipEventCreate(&l->ev1) != hipSuccess
 		    || hipMalloc((void**)&l->d_cnt, sizeof(DevCounters)) != hipSuccess)
@@ -252,6 +252,7 @@ void sync_lane_scene(JpContext* c, JpContext* l)
 	l->persist = c->persist; l->vote = c->vote; l->shade_sort = c->shade_sort; l->class_mask = c->class_mask;
 	l->has_null_material = c->has_null_material; l->tables_in_lds = c->tables_in_lds; l->stage_nee = c->stage_nee; l->shade_lds_bytes = c->shade_lds_bytes;
 	l->profiling = c->profiling;
+	l->opt = c->opt;                                                 // render_one(lane) reads max_slots / compact_regions from its own context
 }
 
 

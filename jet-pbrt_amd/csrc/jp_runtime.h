@@ -51,7 +51,7 @@ static void options_from_environment(JpOptions& o)
 struct JpContext
 {
 	int device = 0;
-	JpOptions opt, opt_env;                                      // the options in force; their initial value (defaults + environment, jp_create_context)
+	JpOptions opt{}, opt_env{};                                    // the options in force; their initial value (defaults + environment, jp_create_context)
 	hipStream_t stream = nullptr;
 	int n_cus = 256;
 	// scene
