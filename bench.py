@@ -181,6 +181,7 @@ def main():
     ap.add_argument("--cpu-bands", type=int, default=2, help="20-row bands rendered by the CPU oracle at the full spp (Cornell parity sample)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the pool's driver supports dmabuf IPC only: RCCL across processes fails without it (already exported on the GPU boxes)
     import numpy as np
     import torch
     import jet_pbrt_amd as jp
