@@ -651,6 +651,25 @@ def test_two_lanes_render_the_same_film_as_one(H, gpu_ctx, monkeypatch):
     gpu_ctx.set_options()
 
 
+def test_stream_lanes_render_under_the_parents_options(H, gpu_ctx):
+    """The extra stream lanes are contexts of their own inside the library; the options set on the caller's context (JpOptions, jp_set_options)
+    must hold for them too.  max_slots caps a batch at 2 samples per pixel of a lane's share here, so every lane needs 4 batches for 8 spp:
+    (max_depth + 1) closest-hit launches per batch and lane, counted by the per-launch events -- and the film does not change"""
+    hb, sp = _scene(H, "cornell", 96, 96)
+    gpu_ctx.upload(sp)
+    p = H.jp.render_params(96, 96, 8, 5, 7)
+    gpu_ctx.set_options(lanes=3, lane_rows=32)
+    gpu_ctx.set_profiling(True)
+    free = gpu_ctx.render(p); c0 = gpu_ctx.counters(); L = int(gpu_ctx.build_info().lanes_last_render)
+    assert L == 3 and c0.extend_launches == 3 * 6, (L, c0.extend_launches)
+    gpu_ctx.set_options(lanes=3, lane_rows=32, max_slots=2 * 32 * 96)
+    capped = gpu_ctx.render(p); c1 = gpu_ctx.counters()
+    gpu_ctx.set_profiling(False); gpu_ctx.set_options()
+    assert c1.extend_launches == 3 * 4 * 6, c1.extend_launches
+    assert np.array_equal(free.view(np.uint32), capped.view(np.uint32))
+    assert (c0.samples, c0.closest_rays, c0.shadow_rays) == (c1.samples, c1.closest_rays, c1.shadow_rays)
+
+
 def test_full_material_benchmark_size(H, gpu_ctx):
     """BASELINE.json configs[2] (512x512x1024 spp, full bsdf.cc + microfacet.cc materials): full-spp parity on two whole
     bands against the oracle, ray statistics, clamping; runs on two stream lanes like the bench"""
