@@ -130,12 +130,17 @@ class RefBackend(scenes.HostBackend):
         return out
 
 
-def oracle_render(scene_ptr, params, nthreads=8, watertight=False):
+def oracle_render(scene_ptr, params, nthreads=8, watertight=False, rand_seed=1):
     """watertight=True: the reference's arithmetic with a conservative box test (oracle/pt_oracle.cc box_hit), i.e. without
-    the hits the reference's own BVH drops on finely tessellated meshes"""
+    the hits the reference's own BVH drops on finely tessellated meshes.
+    rand_seed: the oracle rebuilds the reference's BVH, whose split axes come from libc rand() (bvh.h:61); every render starts from the state a fresh
+    reference process has (srand(1)), so that a film on a mesh -- where the hits in the fp32 acceptance fringe depend on that tree -- does not depend on how many
+    trees this process (or a library thread calling rand()) has built before.  None: leave the state alone (tools that sweep it)."""
     film = np.zeros((params.height, params.width, 3), np.float32)
     cnt = jp.JpCounters()
     L = oracle_lib()
+    if rand_seed is not None:
+        libc_srand(rand_seed)
     L.jp_oracle_set_watertight(1 if watertight else 0)
     try:
         st = L.jp_oracle_render(scene_ptr, C.byref(params), nthreads, ptr(film), C.byref(cnt))
