@@ -194,6 +194,13 @@ def build_random_scene(be, W, Hh, seed, n_tris=120, tmpdir=None):
     return be
 
 
+def oracle_scene(L, scene_ptr, rand_seed=1):
+    """jp_oracle_scene_new from the rand() state of a fresh reference process (see oracle_render)"""
+    if rand_seed is not None:
+        libc_srand(rand_seed)
+    return L.jp_oracle_scene_new(scene_ptr)
+
+
 def libc_srand(seed=1):
     """the reference BVH draws its split axes from libc rand() (bvh.h:61); reset it so that the compiled
     reference and the restatement build the same tree."""

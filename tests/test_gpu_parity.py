@@ -77,7 +77,7 @@ def test_trace_records_bit_exact_vs_golden_and_oracle(H, gpu_ctx, kat, name):
     d[m // 50: m // 25, 1] = 0.0
     tmin = np.full(m, 0.001, np.float32); tmax = np.where(rng.random(m) < 0.5, np.inf, rng.random(m) * 400).astype(np.float32)
     hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
-    L = H.oracle_lib(); oh = L.jp_oracle_scene_new(sp)
+    L = H.oracle_lib(); oh = H.oracle_scene(L, sp)
     ohit = np.zeros(m, np.int32); ot = np.zeros(m, np.float32); oprim = np.zeros(m, np.int32); onrm = np.zeros((m, 3), np.float32); opos = np.zeros((m, 3), np.float32)
     L.jp_oracle_trace(oh, m, H.ptr(o), H.ptr(d), H.ptr(tmin), H.ptr(tmax), H.ptr(ohit), H.ptr(ot), H.ptr(oprim), H.ptr(onrm), H.ptr(opos))
     L.jp_oracle_scene_free(oh)
@@ -410,7 +410,7 @@ def test_random_scenes(H, gpu_ctx, tmp_path, seed, n_tris):
     d = rng.normal(size=(m, 3)).astype(np.float32); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     tmin = np.full(m, 0.001, np.float32); tmax = np.full(m, np.inf, np.float32)
     hit, t, prim, nrm = gpu_ctx.trace(o, d, tmin, tmax)
-    L = H.oracle_lib(); oh = L.jp_oracle_scene_new(sp)
+    L = H.oracle_lib(); oh = H.oracle_scene(L, sp)
     ohit = np.zeros(m, np.int32); ot = np.zeros(m, np.float32); oprim = np.zeros(m, np.int32); onrm = np.zeros((m, 3), np.float32); opos = np.zeros((m, 3), np.float32)
     L.jp_oracle_trace(oh, m, H.ptr(o), H.ptr(d), H.ptr(tmin), H.ptr(tmax), H.ptr(ohit), H.ptr(ot), H.ptr(oprim), H.ptr(onrm), H.ptr(opos))
     L.jp_oracle_scene_free(oh)
@@ -489,7 +489,7 @@ def test_wide_bvh_closest_hit_records(H, gpu_ctx, tmp_path, monkeypatch):
     d = rng.normal(size=(m, 3)).astype(np.float32); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     d[:1000, 2] = 0.0
     tmin = np.full(m, 0.001, np.float32); tmax = np.where(rng.random(m) < 0.5, np.inf, rng.random(m) * 6).astype(np.float32)
-    L = H.oracle_lib(); oh = L.jp_oracle_scene_new(sp)
+    L = H.oracle_lib(); oh = H.oracle_scene(L, sp)
     ohit = np.zeros(m, np.int32); ot = np.zeros(m, np.float32); oprim = np.zeros(m, np.int32); onrm = np.zeros((m, 3), np.float32); opos = np.zeros((m, 3), np.float32)
     L.jp_oracle_trace(oh, m, H.ptr(o), H.ptr(d), H.ptr(tmin), H.ptr(tmax), H.ptr(ohit), H.ptr(ot), H.ptr(oprim), H.ptr(onrm), H.ptr(opos))
     L.jp_oracle_scene_free(oh)
@@ -504,7 +504,7 @@ def test_wide_bvh_closest_hit_records(H, gpu_ctx, tmp_path, monkeypatch):
 # ---- device-side hierarchy build (jet-pbrt_amd/csrc/jp_lbvh.h) ----------------------------
 def _oracle_trace(H, sp, o, d, tmin, tmax):
     m = o.shape[0]
-    L = H.oracle_lib(); oh = L.jp_oracle_scene_new(sp)
+    L = H.oracle_lib(); oh = H.oracle_scene(L, sp)
     ohit = np.zeros(m, np.int32); ot = np.zeros(m, np.float32); oprim = np.zeros(m, np.int32); onrm = np.zeros((m, 3), np.float32); opos = np.zeros((m, 3), np.float32)
     L.jp_oracle_trace(oh, m, H.ptr(o), H.ptr(d), H.ptr(tmin), H.ptr(tmax), H.ptr(ohit), H.ptr(ot), H.ptr(oprim), H.ptr(onrm), H.ptr(opos))
     L.jp_oracle_scene_free(oh)
@@ -847,7 +847,7 @@ def test_certified_walk_against_the_verbatim_walk(H, gpu_ctx):
     pxy = np.stack([rng.uniform(0, W, n), rng.uniform(0, Hh, n)], 1).astype(np.float32)
     o = np.zeros((n, 3), np.float32); d = np.zeros((n, 3), np.float32)
     L = H.oracle_lib(); H.libc_srand(1)
-    oh = L.jp_oracle_scene_new(vsp); L.jp_oracle_camera_rays(oh, n, H.ptr(pxy), H.ptr(o), H.ptr(d)); L.jp_oracle_scene_free(oh)
+    oh = H.oracle_scene(L, vsp); L.jp_oracle_camera_rays(oh, n, H.ptr(pxy), H.ptr(o), H.ptr(d)); L.jp_oracle_scene_free(oh)
     tmin = np.full(n, 0.001, np.float32); tmax = np.full(n, np.inf, np.float32)
     p = H.jp.render_params(W, Hh, 16)
     vctx = H.jp.Context(0)
@@ -1417,7 +1417,7 @@ def test_four_wide_quantised_tree_hit_records_and_film(H, monkeypatch):
         film4 = c4.render(H.jp.render_params(W, Hh, spp, 5, 9)); cnt4 = c4.counters()
     finally:
         c4.close()
-    L = H.oracle_lib(); oh = L.jp_oracle_scene_new(sp)
+    L = H.oracle_lib(); oh = H.oracle_scene(L, sp)
     ohit = np.zeros(m, np.int32); ot = np.zeros(m, np.float32); oprim = np.zeros(m, np.int32); onrm = np.zeros((m, 3), np.float32); opos = np.zeros((m, 3), np.float32)
     L.jp_oracle_trace(oh, m, H.ptr(o), H.ptr(d), H.ptr(tmin), H.ptr(tmax), H.ptr(ohit), H.ptr(ot), H.ptr(oprim), H.ptr(onrm), H.ptr(opos))
     L.jp_oracle_scene_free(oh)

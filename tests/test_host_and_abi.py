@@ -239,7 +239,7 @@ def test_reference_tree_builder_reproduces_the_reference_topology(H):
         sys.setrecursionlimit(10000)
         walk(0)
         H.libc_srand(1)                                           # the reference process' default rand() state
-        Lo = H.oracle_lib(); oh = Lo.jp_oracle_scene_new(hb.flatten())
+        Lo = H.oracle_lib(); oh = H.oracle_scene(Lo, hb.flatten())
         ob = np.zeros((4 * s.n_primitives + 8, 6), np.float32); ok = np.zeros(4 * s.n_primitives + 8, np.int32); oo = np.zeros(s.n_primitives, np.int32)
         n = Lo.jp_oracle_tree_dump(oh, H.ptr(ob), H.ptr(ok), H.ptr(oo), len(ok))
         Lo.jp_oracle_scene_free(oh)

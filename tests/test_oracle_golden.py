@@ -62,7 +62,7 @@ def test_stock_stream(H, kat):
 def test_camera_trace_light_li_kats(H, kat, name):
     hb, sp = _scene(H, name)
     L = H.oracle_lib()
-    oh = L.jp_oracle_scene_new(sp)
+    oh = H.oracle_scene(L, sp)
     try:
         n = kat[name + "_cam_pxy"].shape[0]
         o = np.zeros((n, 3), np.float32); d = np.zeros((n, 3), np.float32)
@@ -101,7 +101,7 @@ def test_bsdf_kats(H, kat):
     """FBSDF::Evalf / Sample of every material kind (matte, metal, glass, mirror, remapped plastic) on random frames."""
     hb, sp = _scene(H, "misc")
     L = H.oracle_lib()
-    oh = L.jp_oracle_scene_new(sp)
+    oh = H.oracle_scene(L, sp)
     try:
         nn = np.ascontiguousarray(kat["bsdf_n"]); wo = np.ascontiguousarray(kat["bsdf_wo"]); wi = np.ascontiguousarray(kat["bsdf_wi"])
         u2 = np.ascontiguousarray(kat["bsdf_u2"]); us = np.ascontiguousarray(kat["bsdf_us"]); n = nn.shape[0]
