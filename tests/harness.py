@@ -135,7 +135,8 @@ def oracle_render(scene_ptr, params, nthreads=8, watertight=False, rand_seed=1):
     the hits the reference's own BVH drops on finely tessellated meshes.
     rand_seed: the oracle rebuilds the reference's BVH, whose split axes come from libc rand() (bvh.h:61); every render starts from the state a fresh
     reference process has (srand(1)), so that a film on a mesh -- where the hits in the fp32 acceptance fringe depend on that tree -- does not depend on how many
-    trees this process (or a library thread calling rand()) has built before.  None: leave the state alone (tools that sweep it)."""
+    trees this process has built before -- nor on the HIP runtime: libamd_comgr calls srand() with a seed of its own and rand() whenever it loads a code object
+    (tools/randtrace: 66 calls and one srand in the main thread of a GPU test run), which used to make every later un-seeded oracle tree a different one per run.  None: leave the state alone (tools that sweep it)."""
     film = np.zeros((params.height, params.width, 3), np.float32)
     cnt = jp.JpCounters()
     L = oracle_lib()
