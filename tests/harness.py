@@ -104,6 +104,15 @@ class RefBackend(scenes.HostBackend):
     def _new(self, name):
         self.h = C.c_void_p(self.L.ref_scene_new(name.encode()))
 
+    rand_seed = 1
+
+    def preprocess(self):
+        """FScene::Preprocess (scene.cc:11-23) grows the tree from libc rand(): from the state a fresh reference process has, whatever this process did before
+        (oracle_render; set rand_seed = None on the instance to leave the state alone)"""
+        if self.rand_seed is not None:
+            libc_srand(self.rand_seed)
+        super().preprocess()
+
     def render(self, W, H, spp, maxdepth=5, sampler_mode=1, seed=1234, nthreads=8):
         film = np.zeros((H, W, 3), np.float32)
         st = self.L.ref_render(self.h, W, H, spp, maxdepth, sampler_mode, seed, nthreads, ptr(film))
